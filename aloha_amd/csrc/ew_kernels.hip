@@ -1,0 +1,109 @@
+// ew_kernels.hip -- element-wise modular ALU, automorphism and roll kernels for gfx950.
+//
+// Reference units replaced: modalu add/sub/mul/mod paths (src/vp/vxu/modalu.sv:196-249),
+// the vaut/vroli address math + 14-stage routing network (src/vp/vxu/vxu_lane.sv:594-598,
+// src/vp/iconn/iconn_top.sv:72-133).  All are HBM-bound streams: 16 B per lane per access
+// (two coefficients), grid-strided, nothing staged through LDS.  The permutations are written
+// as gathers so the stores stay coalesced.
+#include "kernels.hpp"
+#include "modarith.hpp"
+
+namespace aloha {
+namespace k {
+
+namespace {
+
+struct alignas(16) u64x2 { u64 x, y; };
+
+template <int OP>
+__device__ __forceinline__ u64 ew_one(u64 a, u64 b, u64 s, u64 sp, const ModCtx &m) {
+  const u64 q = m.q;
+  // every ALU input passes ONE conditional subtraction (modalu.sv:44-46)
+  a = csub(a, q);
+  if (OP == EW_MUL_VV || OP == EW_ADD_VV || OP == EW_SUB_VV) b = csub(b, q);
+  switch (OP) {
+    case EW_MUL_VV: return mulmod_barrett(a, b, q, m.mu);
+    case EW_MUL_VS: return csub(mul_shoup_2q(a, s, sp, q), q);
+    case EW_ADD_VV: return addmod(a, b, q);
+    case EW_ADD_VS: return addmod(a, s, q);
+    case EW_SUB_VV: return submod(a, b, q);
+    case EW_SUB_VS: return submod(a, s, q);
+    case EW_SUB_SV: return submod(s, a, q);
+    case EW_MOD:    return csub(a, q);      // a*1 through the Barrett unit (modalu.sv:164)
+    case EW_CP:     return csub(a, q);      // a + 0 then the adder's conditional subtract (expander.v:396-417)
+  }
+  return 0;
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void ew_kernel(u64x2 *__restrict__ d, const u64x2 *__restrict__ a,
+                                                 const u64x2 *__restrict__ b, u64 s, u64 sp, ModCtx m,
+                                                 uint32_t n2) {
+  constexpr bool VV = (OP == EW_MUL_VV || OP == EW_ADD_VV || OP == EW_SUB_VV);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+    u64x2 va = a[i];
+    u64x2 vb = VV ? b[i] : u64x2{0, 0};
+    u64x2 r;
+    r.x = ew_one<OP>(va.x, vb.x, s, sp, m);
+    r.y = ew_one<OP>(va.y, vb.y, s, sp, m);
+    d[i] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void vaut_kernel(u64 *__restrict__ out, const u64 *__restrict__ in,
+                                                   uint32_t n, u64 q, uint32_t kk, uint32_t kinv) {
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+    uint32_t i = (j * kinv) & (n - 1);                 // the source index that lands on j
+    uint32_t t = (i * kk) & (2 * n - 1);               // i*k mod 2N  (t mod N == j)
+    u64 v = in[i];
+    out[j] = (t >= n) ? q - v : v;                     // raw q - x: a flipped 0 is stored as q (vxu_lane.sv:598)
+  }
+}
+
+__global__ __launch_bounds__(256) void vroli_kernel(u64 *__restrict__ out, const u64 *__restrict__ in,
+                                                    uint32_t n, uint32_t s) {
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256)
+    out[j] = in[(j + s) & (n - 1)];
+}
+
+inline uint32_t grid_for(uint32_t work_items) {
+  uint32_t g = (work_items + 255) / 256;
+  return g > 2048 ? 2048 : (g ? g : 1);
+}
+
+}  // namespace
+
+hipError_t ew(hipStream_t st, EwOp op, u64 *d, const u64 *a, const u64 *b, u64 s, u64 sp, ModCtx m,
+              uint32_t n) {
+  const uint32_t n2 = n / 2;
+  dim3 g(grid_for(n2)), blk(256);
+  auto D = reinterpret_cast<u64x2 *>(d);
+  auto A = reinterpret_cast<const u64x2 *>(a);
+  auto B = reinterpret_cast<const u64x2 *>(b);
+  switch (op) {
+#define ALOHA_EW_CASE(OPC) \
+  case OPC: hipLaunchKernelGGL(ew_kernel<OPC>, g, blk, 0, st, D, A, B, s, sp, m, n2); break;
+    ALOHA_EW_CASE(EW_MUL_VV) ALOHA_EW_CASE(EW_MUL_VS) ALOHA_EW_CASE(EW_ADD_VV) ALOHA_EW_CASE(EW_ADD_VS)
+    ALOHA_EW_CASE(EW_SUB_VV) ALOHA_EW_CASE(EW_SUB_VS) ALOHA_EW_CASE(EW_SUB_SV) ALOHA_EW_CASE(EW_MOD)
+    ALOHA_EW_CASE(EW_CP)
+#undef ALOHA_EW_CASE
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t vaut(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 q, u64 kk, u64 kinv) {
+  const uint32_t n = 1u << logn;
+  hipLaunchKernelGGL(vaut_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, in, n, q, (uint32_t)kk,
+                     (uint32_t)kinv);
+  return hipGetLastError();
+}
+
+hipError_t vroli(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 s) {
+  const uint32_t n = 1u << logn;
+  hipLaunchKernelGGL(vroli_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, in, n, (uint32_t)s);
+  return hipGetLastError();
+}
+
+}  // namespace k
+}  // namespace aloha

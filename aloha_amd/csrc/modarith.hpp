@@ -1,0 +1,195 @@
+// modarith.hpp -- 64-bit modular arithmetic for gfx950 (CDNA4), device side.
+//
+// The reference's modalu (src/vp/vxu/modalu.sv) is a pipelined Barrett unit on 23-bit DSP
+// slices; on CDNA4 the natural unit is the 32x32->64 multiply-add (v_mad_u64_u32) and the
+// 32-bit low/high multiplies.  All moduli are primes q with 2^59 < q < 2^60, so values up to
+// 16q fit a 64-bit register: butterflies are evaluated lazily (Harvey) in [0, 4q) / [0, 2q)
+// and canonicalised once at the end -- the canonical residues are identical to the
+// reference's fully reduced ones.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aloha {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define ALOHA_DEV __device__ __forceinline__
+
+ALOHA_DEV u32 lo32(u64 x) { return (u32)x; }
+ALOHA_DEV u32 hi32(u64 x) { return (u32)(x >> 32); }
+ALOHA_DEV u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+// The three multiplier instructions, pinned by (non-volatile) inline asm: written as C,
+// LLVM's InstCombine re-merges the 32-bit limb algebra below into generic 64-bit multiplies
+// and the hand-counted issue budget is lost.  The asm statements have only VGPR/SGPR
+// operands and no memory side effects, so the scheduler is free to move, CSE or delete them.
+// v_mad_u64_u32 also writes a carry-out SGPR pair (VOP3B); it is a dead dummy output here.
+// "_s" variants take the second factor from an SGPR (wave-uniform twiddle / modulus limbs).
+ALOHA_DEV u64 mad32(u32 a, u32 b, u64 c) {
+  u64 r, cy;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+ALOHA_DEV u64 mad32_s(u32 a, u32 b, u64 c) {
+  u64 r, cy;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cy) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+ALOHA_DEV u32 mullo32(u32 a, u32 b) {
+  u32 r;
+  asm("v_mul_lo_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+ALOHA_DEV u32 mullo32_s(u32 a, u32 b) {
+  u32 r;
+  asm("v_mul_lo_u32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+ALOHA_DEV u32 mulhi32(u32 a, u32 b) {
+  u32 r;
+  asm("v_mul_hi_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+ALOHA_DEV u32 mulhi32_s(u32 a, u32 b) {
+  u32 r;
+  asm("v_mul_hi_u32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+
+// ---- canonicalisation ------------------------------------------------------------------
+ALOHA_DEV u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }          // [0,2q) -> [0,q)
+ALOHA_DEV u64 addmod(u64 a, u64 b, u64 q) { return csub(a + b, q); }        // a,b < q
+ALOHA_DEV u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+// halfred.sv:23-26
+ALOHA_DEV u64 halfmod(u64 x, u64 q) { return (x >> 1) + ((x & 1) ? ((q + 1) >> 1) : 0); }
+
+// ---- Shoup multiplication by a precomputed constant --------------------------------------
+// w < q, wp = floor(w * 2^64 / q).  For ANY 64-bit a:  a*w - floor(a*wp / 2^64) * q  lies in
+// [0, 2q) and is congruent to a*w.
+
+// Exact-quotient form (compiler-scheduled 64x64 high multiply): result in [0, 2q).
+ALOHA_DEV u64 mul_shoup_2q(u64 a, u64 w, u64 wp, u64 q) {
+  u64 qhat = __umul64hi(a, wp);
+  return a * w - qhat * q;
+}
+
+// Approximate-quotient form: the low x low partial product and the carries out of the low
+// half are dropped, so qhat is short by at most 2 and the result lies in [0, 4q) (< 2^62).
+// 9 multiplier issues in all (3 for qhat, 6 for the two low products), no carry chains.
+// UNI = the constant (w, wp) is wave-uniform and lives in SGPRs.
+template <bool UNI>
+ALOHA_DEV u64 shoup_qhat_approx(u64 a, u64 wp) {
+  u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(wp), w1 = hi32(wp);
+  u32 c = UNI ? mulhi32_s(a1, w0) : mulhi32(a1, w0);
+  u32 d = UNI ? mulhi32_s(a0, w1) : mulhi32(a0, w1);
+  u64 cd = (u64)c + d;
+  return UNI ? mad32_s(a1, w1, cd) : mad32(a1, w1, cd);
+}
+
+// low 64 bits of a*w + b*nq  (nq = 2^64 - q, always wave-uniform): the two 64-bit low
+// products share one accumulator chain, every addition folded into a multiply-add.
+template <bool UNI>
+ALOHA_DEV u64 mullo2_acc(u64 a, u64 w, u64 b, u64 nq) {
+  u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(w), w1 = hi32(w);
+  u32 b0 = lo32(b), b1 = hi32(b), n0 = lo32(nq), n1 = hi32(nq);
+  u32 x0 = UNI ? mullo32_s(a1, w0) : mullo32(a1, w0);
+  u32 x1 = UNI ? mullo32_s(a0, w1) : mullo32(a0, w1);
+  u32 x2 = mullo32_s(b1, n0);
+  u32 x3 = mullo32_s(b0, n1);
+  u32 cross = x0 + x1 + x2 + x3;                      // only the low 32 bits matter
+  u64 acc = UNI ? mad32_s(a0, w0, pack64(0, cross)) : mad32(a0, w0, pack64(0, cross));
+  return mad32_s(b0, n0, acc);
+}
+
+template <bool UNI>
+ALOHA_DEV u64 mul_shoup_4q(u64 a, u64 w, u64 wp, u64 nq) {
+  u64 qhat = shoup_qhat_approx<UNI>(a, wp);
+  return mullo2_acc<UNI>(a, w, qhat, nq);
+}
+
+// ---- relaxed-range Cooley-Tukey butterflies ------------------------------------------------
+// The Shoup product reduces ANY 64-bit input, so only the un-multiplied operand X grows:
+// (X, Y) -> (X + T, X - T + C) with T = Y*w mod q in [0, C), C a multiple of q.  Both outputs
+// are < bound(X) + C; with q < 2^60 sixteen q's fit a register, so no per-butterfly
+// conditional is needed (corrections are applied once per several stages by the caller).
+// The sum X + T is folded into the multiply-add chain (T is never materialised) and the
+// second output comes from out0 + out1 = 2X + C.
+
+// exact quotient (4 multiplier issues): T in [0, 2q), C = 2q.  twoq2 = 2q.
+template <bool UNI>
+ALOHA_DEV u64 shoup_qhat_exact(u64 a, u64 wp) {
+  u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(wp), w1 = hi32(wp);
+  u32 t = UNI ? mulhi32_s(a0, w0) : mulhi32(a0, w0);
+  u64 m1 = UNI ? mad32_s(a1, w0, (u64)t) : mad32(a1, w0, (u64)t);                 // < 2^64
+  u64 m2 = UNI ? mad32_s(a0, w1, (u64)lo32(m1)) : mad32(a0, w1, (u64)lo32(m1));   // < 2^64
+  u64 m3 = UNI ? mad32_s(a1, w1, (u64)hi32(m1)) : mad32(a1, w1, (u64)hi32(m1));   // < 2^64
+  return m3 + hi32(m2);
+}
+
+// out0 = X + (a*w + qhat*nq)  (mod 2^64): the X + T sum rides on the accumulator chain.
+template <bool UNI>
+ALOHA_DEV u64 shoup_fold_add(u64 X, u64 a, u64 w, u64 qhat, u64 nq) {
+  u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(w), w1 = hi32(w);
+  u32 b0 = lo32(qhat), b1 = hi32(qhat), n0 = lo32(nq), n1 = hi32(nq);
+  u32 x0 = UNI ? mullo32_s(a1, w0) : mullo32(a1, w0);
+  u32 x1 = UNI ? mullo32_s(a0, w1) : mullo32(a0, w1);
+  u32 x2 = mullo32_s(b1, n0);
+  u32 x3 = mullo32_s(b0, n1);
+  u32 hi = hi32(X) + x0 + x1 + x2 + x3;
+  u64 acc = UNI ? mad32_s(a0, w0, pack64(lo32(X), hi)) : mad32(a0, w0, pack64(lo32(X), hi));
+  return mad32_s(b0, n0, acc);
+}
+
+template <bool UNI, bool EXACT>
+ALOHA_DEV void ct_bfly(u64 &X, u64 &Y, u64 w, u64 wp, u64 nq, u64 C) {
+  u64 qhat = EXACT ? shoup_qhat_exact<UNI>(Y, wp) : shoup_qhat_approx<UNI>(Y, wp);
+  u64 o0 = shoup_fold_add<UNI>(X, Y, w, qhat, nq);
+  u64 o1 = (X << 1) + C - o0;
+  X = o0;
+  Y = o1;
+}
+
+// q == 1 (mod 2^32) (the shape of the reference's q0, q1: src/top/h2_top_no_axilite.sv:31-32):
+// nq = 2^64 - q has low word 0xFFFFFFFF, so qhat*nq needs ONE multiply:
+//   qhat*nq = (qhat*n1' << 32) - qhat  with n1' = hi32(nq) + 1  (mod 2^64).
+template <bool UNI, bool EXACT>
+ALOHA_DEV void ct_bfly_p32(u64 &X, u64 &Y, u64 w, u64 wp, u64 nq, u64 C) {
+  u64 a = Y;
+  u64 qhat = EXACT ? shoup_qhat_exact<UNI>(a, wp) : shoup_qhat_approx<UNI>(a, wp);
+  u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(w), w1 = hi32(w);
+  u32 x0 = UNI ? mullo32_s(a1, w0) : mullo32(a1, w0);
+  u32 x1 = UNI ? mullo32_s(a0, w1) : mullo32(a0, w1);
+  u32 x3 = mullo32_s(lo32(qhat), hi32(nq) + 1);
+  u32 hi = hi32(X) + x0 + x1 + x3;
+  u64 acc = UNI ? mad32_s(a0, w0, pack64(lo32(X), hi)) : mad32(a0, w0, pack64(lo32(X), hi));
+  u64 o0 = acc - qhat;
+  u64 o1 = (X << 1) + C - o0;
+  X = o0;
+  Y = o1;
+}
+
+// conditional subtraction by the borrow of the subtraction itself (exact 64-bit compare
+// for free): x >= m ? x - m : x
+ALOHA_DEV u64 csub_borrow(u64 x, u64 m) {
+  u64 d = x - m;
+  return x < m ? x : d;
+}
+
+// ---- general product of two residues (Barrett, single-word ratio) -----------------------
+// a, b < 2^60 (so z = a*b < 2^120); mu = floor(2^121 / q), nq = 2^64 - q.
+// x1 = z >> 57 (63 bit), qhat = floor(x1 * mu / 2^64).  With x1 <= z/2^57 < x1+1 and
+// mu <= 2^121/q < mu+1:  0 <= z/q - x1*mu/2^64 < (x1 + mu + 1)/2^64 < 0.76, so qhat is
+// floor(z/q) or one less, the remainder estimate lies in [0, 2q) and ONE conditional
+// subtraction canonicalises it.  Same scheme as the reference's modmul.sv:150-251 (Barrett,
+// alpha = n+1) re-cut for 64-bit words.
+ALOHA_DEV u64 mulmod_barrett(u64 a, u64 b, u64 q, u64 mu) {
+  u64 zl = a * b;
+  u64 zh = __umul64hi(a, b);
+  u64 x1 = (zh << 7) | (zl >> 57);
+  u64 qhat = __umul64hi(x1, mu);
+  return csub(zl - qhat * q, q);
+}
+
+}  // namespace aloha

@@ -1,0 +1,555 @@
+// vp_engine.cpp -- host side of libaloha_vp.so: the VP as an ISA machine on one MI355X.
+//
+// What of the reference lives here (and what does not):
+//   * instruction ROM + decoder          src/vp/sequncer/inst_rom.v:32-35, expander.v:65-700
+//   * sequential issue (one op in flight) src/vp/sequncer/seq_top.v:343-513  -> a HIP stream
+//   * vector register file (32 x N u64)  src/vp/vxu/vxu_rfbank.sv:13        -> one HBM slab
+//   * SPM / KSK memories                 src/mem_buf/spm.sv:12, ksk_mem.sv:12 -> two HBM slabs
+//   * vle/vse address generation         src/vp/vmu/addr_gen.v:44, vp_top_full.sv:105-117
+//   * twiddle ROM contents               sim/vp/tf_rom_generator/tf_rom_generator.sv:28-111
+// The queues, FSMs, AXI DMA and pipeline timing of the RTL have no equivalent: semantics are
+// plain sequential.  There is no CPU compute path: without a gfx950 device every
+// entry point fails with ALOHA_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/aloha_vp.h"
+#include "kernels.hpp"
+#include "numtheory.hpp"
+
+using aloha::k::LimbJob;
+using aloha::k::ModCtx;
+using aloha::k::PrimeDev;
+using aloha::k::TileDesc;
+using aloha::k::TwiddleDev;
+typedef unsigned long long u64;
+
+namespace {
+
+constexpr uint32_t kLanes = 128;
+constexpr uint32_t kMaxPrimes = 4096;
+
+struct PrimeSlot {
+  uint64_t q = 0;
+  unsigned logn = 0;
+  PrimeDev dev{};
+  u64 *d_tables = nullptr;       // one allocation: fwd | inv | fwd_blk | inv_blk
+};
+
+struct BatchPlan {               // cached device-side description of the last batched transform
+  std::vector<LimbJob> jobs;     // 2*count entries
+  unsigned logn = 0;
+  uint32_t n_lds = 0, n_glb = 0;
+  bool valid = false;
+};
+
+}  // namespace
+
+struct aloha_vp {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  uint32_t flags = 0;
+  uint64_t spm_rows = 0, ksk_rows = 0;
+  unsigned max_logn = 16;
+  u64 *d_spm = nullptr, *d_ksk = nullptr, *d_vreg = nullptr, *d_scratch = nullptr;
+  // architectural state (vxu_top.sv:106-118)
+  uint64_t vl_bits = 0, q = 0, mu = 0;
+  std::vector<uint32_t> inst;
+  std::vector<uint64_t> imm;
+  // primes / twiddles
+  std::vector<PrimeSlot> slots;
+  std::map<std::pair<uint64_t, unsigned>, uint32_t> slot_of;
+  PrimeDev *d_primes = nullptr;
+  // batched-transform staging
+  LimbJob *d_jobs = nullptr;
+  TileDesc *d_tiles = nullptr;
+  size_t jobs_cap = 0, tiles_cap = 0;
+  BatchPlan plan;
+  aloha_vp_stats stats{};
+  std::string err;
+};
+
+namespace {
+
+aloha_status fail(aloha_vp *vp, aloha_status s, const char *fmt, ...) {
+  if (vp) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    vp->err = buf;
+  }
+  return s;
+}
+
+#define HIPCK(vp, expr)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(vp, ALOHA_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+  } while (0)
+
+u64 *vreg(aloha_vp *vp, unsigned r) { return vp->d_vreg + ((size_t)r << vp->max_logn); }
+
+aloha_status vl_logn(uint64_t vl_bits, unsigned max_logn, unsigned *logn) {
+  if (vl_bits % 64) return ALOHA_ERR_VL;
+  const uint64_t n = vl_bits / 64;
+  for (unsigned l = 10; l <= 16; l++)
+    if (n == (1ull << l)) {
+      if (l > max_logn) return ALOHA_ERR_VL;
+      *logn = l;
+      return ALOHA_OK;
+    }
+  return ALOHA_ERR_VL;                               // ntt_fsm.sv:59-65 admits log2 N in 10..16
+}
+
+bool modulus_ok(uint64_t q) { return q > (1ull << 59) && q < (1ull << 60) && aloha::nt::is_prime(q); }
+
+ModCtx modctx(uint64_t q) { return ModCtx{q, 0 - q, aloha::nt::barrett_mu(q)}; }
+
+// Twiddle set for (q, N): generated on first use, kept for the life of the handle.
+aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
+  auto key = std::make_pair(q, logn);
+  auto it = vp->slot_of.find(key);
+  if (it != vp->slot_of.end()) { *out = it->second; return ALOHA_OK; }
+  if (vp->slots.size() >= kMaxPrimes) return fail(vp, ALOHA_ERR_NOMEM, "more than %u (q, N) twiddle sets", kMaxPrimes);
+  if ((q - 1) % (2ull << logn)) return fail(vp, ALOHA_ERR_ROOT, "q = %#llx is not 1 mod 2N (N = 2^%u)", (u64)q, logn);
+  aloha::nt::TwiddleTables tt;
+  if (!aloha::nt::make_twiddles(q, logn, &tt)) return fail(vp, ALOHA_ERR_ROOT, "no primitive 2N-th root mod %#llx", (u64)q);
+  const uint32_t n = 1u << logn, n1 = logn - 8, rows = 1u << n1;
+  const size_t blk_words = (size_t)(1 + rows) * 256 * 2;
+  // blocked layout for the tile kernels: block 0 = W[0..255]; block 1+r, entry 2^s'+i =
+  // W[2^(n1+s') + r*2^s' + i]  (ntt_tile.hip header)
+  std::vector<uint64_t> host(2 * (size_t)n * 2 + 2 * blk_words, 0);
+  uint64_t *fwd = host.data(), *inv = fwd + 2 * (size_t)n, *fblk = inv + 2 * (size_t)n, *iblk = fblk + blk_words;
+  memcpy(fwd, tt.fwd.data(), 2 * (size_t)n * 8);
+  memcpy(inv, tt.inv.data(), 2 * (size_t)n * 8);
+  for (int dir = 0; dir < 2; dir++) {
+    const uint64_t *tab = dir ? inv : fwd;
+    uint64_t *blk = dir ? iblk : fblk;
+    for (uint32_t L = 0; L < 256 && L < n; L++) { blk[2 * L] = tab[2 * L]; blk[2 * L + 1] = tab[2 * L + 1]; }
+    for (uint32_t r = 0; r < rows; r++)
+      for (unsigned s = 0; s < 8; s++)
+        for (uint32_t i = 0; i < (1u << s); i++) {
+          const size_t srci = ((size_t)1 << (n1 + s)) + ((size_t)r << s) + i;
+          const size_t dsti = (size_t)(1 + r) * 256 + (1u << s) + i;
+          blk[2 * dsti] = tab[2 * srci];
+          blk[2 * dsti + 1] = tab[2 * srci + 1];
+        }
+  }
+  PrimeSlot ps;
+  ps.q = q; ps.logn = logn;
+  HIPCK(vp, hipMalloc(&ps.d_tables, host.size() * 8));
+  HIPCK(vp, hipMemcpyAsync(ps.d_tables, host.data(), host.size() * 8, hipMemcpyHostToDevice, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));      // `host` goes out of scope
+  ps.dev.m = modctx(q);
+  ps.dev.tw.fwd = ps.d_tables;
+  ps.dev.tw.inv = ps.d_tables + 2 * (size_t)n;
+  ps.dev.tw.fwd_blk = ps.d_tables + 4 * (size_t)n;
+  ps.dev.tw.inv_blk = ps.d_tables + 4 * (size_t)n + blk_words;
+  ps.dev.tw.n_inv = tt.n_inv;
+  ps.dev.tw.n_inv_shoup = tt.n_inv_shoup;
+  const uint32_t idx = (uint32_t)vp->slots.size();
+  HIPCK(vp, hipMemcpyAsync(vp->d_primes + idx, &ps.dev, sizeof(PrimeDev), hipMemcpyHostToDevice, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  vp->slots.push_back(ps);
+  vp->slot_of[key] = idx;
+  vp->stats.twiddle_builds++;
+  *out = idx;
+  return ALOHA_OK;
+}
+
+// Batched transform of `count` limbs described by (src, dst, slot); the workhorse behind both
+// the vntt/vintt instructions (count = 1) and aloha_vp_ntt_rows.
+aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, unsigned logn, bool inverse) {
+  const uint32_t count = (uint32_t)jobs1.size();
+  if (!count) return ALOHA_OK;
+  // reuse the uploaded plan when the job list repeats (steady-state batches)
+  bool same = vp->plan.valid && vp->plan.logn == logn && vp->plan.jobs.size() == 2 * (size_t)count &&
+              memcmp(vp->plan.jobs.data(), jobs1.data(), count * sizeof(LimbJob)) == 0;
+  if (!same) {
+    std::vector<LimbJob> jobs(jobs1);
+    jobs.resize(2 * (size_t)count);
+    for (uint32_t i = 0; i < count; i++) { jobs[count + i] = jobs1[i]; jobs[count + i].src = jobs1[i].dst; }
+    std::vector<TileDesc> lds, glb;
+    if (!(vp->flags & ALOHA_FLAG_RADIX2_ONLY)) aloha::k::build_row_tiles(jobs.data(), count, logn - 8, lds, glb);
+    if (jobs.size() > vp->jobs_cap) {
+      if (vp->d_jobs) HIPCK(vp, hipFree(vp->d_jobs));
+      vp->jobs_cap = jobs.size() * 2;
+      HIPCK(vp, hipMalloc(&vp->d_jobs, vp->jobs_cap * sizeof(LimbJob)));
+    }
+    const size_t ntiles = lds.size() + glb.size();
+    if (ntiles > vp->tiles_cap) {
+      if (vp->d_tiles) HIPCK(vp, hipFree(vp->d_tiles));
+      vp->tiles_cap = ntiles * 2;
+      HIPCK(vp, hipMalloc(&vp->d_tiles, vp->tiles_cap * sizeof(TileDesc)));
+    }
+    // the previous plan may still be read by kernels in flight on the stream: stream-ordered copies
+    HIPCK(vp, hipMemcpyAsync(vp->d_jobs, jobs.data(), jobs.size() * sizeof(LimbJob), hipMemcpyHostToDevice, vp->stream));
+    if (!lds.empty()) HIPCK(vp, hipMemcpyAsync(vp->d_tiles, lds.data(), lds.size() * sizeof(TileDesc), hipMemcpyHostToDevice, vp->stream));
+    if (!glb.empty()) HIPCK(vp, hipMemcpyAsync(vp->d_tiles + lds.size(), glb.data(), glb.size() * sizeof(TileDesc), hipMemcpyHostToDevice, vp->stream));
+    HIPCK(vp, hipStreamSynchronize(vp->stream));    // pageable sources go out of scope
+    vp->plan.jobs.swap(jobs);
+    vp->plan.logn = logn;
+    vp->plan.n_lds = (uint32_t)lds.size();
+    vp->plan.n_glb = (uint32_t)glb.size();
+    vp->plan.valid = true;
+  }
+  uint64_t launches = 0;
+  hipError_t e;
+  if (vp->plan.n_lds + vp->plan.n_glb == 0) {
+    e = aloha::k::ntt_radix2_batch(vp->stream, vp->d_jobs, vp->d_primes, count, logn, 0, logn, inverse, true, true, &launches);
+  } else {
+    e = aloha::k::ntt_tile_batch(vp->stream, vp->d_jobs, vp->d_primes, count, logn, inverse, vp->d_tiles,
+                                 vp->plan.n_lds, vp->d_tiles + vp->plan.n_lds, vp->plan.n_glb, &launches);
+  }
+  vp->stats.kernel_launches += launches;
+  if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "transform launch failed: %s", hipGetErrorString(e));
+  return ALOHA_OK;
+}
+
+// vle/vse address: addr_gen.v:44 (imm + cnt<<10) and the pointer select of
+// vp_top_full.sv:105-117: row = imm[47:10] + PTR[imm[63:48]] with PTR 0 src0, 1 src1, 2 rslt,
+// others 0; a LOAD with select 15 reads the KSK memory at csr_ksk_ptr (:113-114).  The RTL
+// keeps 16 row bits; here the range is checked against the configured space instead.
+u64 *mem_rows(aloha_vp *vp, uint64_t imm, bool is_load, const uint64_t csr[4], uint64_t nrows) {
+  const unsigned sel = (unsigned)(imm >> 48);
+  const uint64_t off = (imm & 0xFFFFFFFFFFFFull) >> 10;
+  uint64_t row, rows;
+  u64 *base;
+  if (is_load && sel == 15) { row = off + csr[3]; rows = vp->ksk_rows; base = vp->d_ksk; }
+  else { row = off + (sel == 0 ? csr[0] : sel == 1 ? csr[1] : sel == 2 ? csr[2] : 0); rows = vp->spm_rows; base = vp->d_spm; }
+  if (row > rows || nrows > rows - row) return nullptr;
+  return base + row * kLanes;
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+uint32_t aloha_vp_abi_version(void) { return ALOHA_VP_ABI_VERSION; }
+
+const char *aloha_status_string(aloha_status s) {
+  switch (s) {
+    case ALOHA_OK: return "ok";
+    case ALOHA_ERR_ARG: return "bad argument";
+    case ALOHA_ERR_VL: return "vector length not 64 * 2^k, k in [10,16]";
+    case ALOHA_ERR_MODULUS: return "modulus not a prime in (2^59, 2^60)";
+    case ALOHA_ERR_ROOT: return "modulus has no 2N-th root of unity";
+    case ALOHA_ERR_DECODE: return "undefined instruction encoding";
+    case ALOHA_ERR_BANK: return ".vv operands in the same register bank";
+    case ALOHA_ERR_ADDR: return "memory row out of range";
+    case ALOHA_ERR_AUT: return "even automorphism exponent";
+    case ALOHA_ERR_NOBREAK: return "program ran off the instruction ROM";
+    case ALOHA_ERR_DEVICE: return "HIP device error";
+    case ALOHA_ERR_NOMEM: return "out of memory";
+  }
+  return "unknown";
+}
+
+const char *aloha_vp_last_error(const aloha_vp *vp) { return vp ? vp->err.c_str() : "null handle"; }
+
+aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
+  if (!cfg || !out) return ALOHA_ERR_ARG;
+  *out = nullptr;
+  if (cfg->abi_version != ALOHA_VP_ABI_VERSION) return ALOHA_ERR_ARG;
+  if (cfg->max_log_n < 10 || cfg->max_log_n > 16) return ALOHA_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return ALOHA_ERR_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return ALOHA_ERR_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ALOHA_ERR_DEVICE;   // kernels are gfx950 code objects
+  aloha_vp *vp = new aloha_vp();
+  vp->device = cfg->device;
+  vp->flags = cfg->flags;
+  vp->spm_rows = cfg->spm_rows;
+  vp->ksk_rows = cfg->ksk_rows;
+  vp->max_logn = cfg->max_log_n;
+  vp->inst.assign(ALOHA_IRAM_DEPTH, 0);
+  vp->imm.assign(ALOHA_IRAM_DEPTH, 0);
+  auto bail = [&](const char *what) {
+    fprintf(stderr, "aloha_vp_create: %s failed\n", what);
+    aloha_vp_destroy(vp);
+    return ALOHA_ERR_DEVICE;
+  };
+  if (hipSetDevice(vp->device) != hipSuccess) return bail("hipSetDevice");
+  if (cfg->stream) vp->stream = (hipStream_t)cfg->stream;
+  else {
+    if (hipStreamCreateWithFlags(&vp->stream, hipStreamNonBlocking) != hipSuccess) return bail("hipStreamCreate");
+    vp->own_stream = true;
+  }
+  const size_t vreg_bytes = (size_t)ALOHA_NVREG << (vp->max_logn + 3);
+  if (hipMalloc(&vp->d_spm, (vp->spm_rows ? vp->spm_rows : 1) * (size_t)ALOHA_ROW_BYTES) != hipSuccess) return bail("hipMalloc(spm)");
+  if (hipMalloc(&vp->d_ksk, (vp->ksk_rows ? vp->ksk_rows : 1) * (size_t)ALOHA_ROW_BYTES) != hipSuccess) return bail("hipMalloc(ksk)");
+  if (hipMalloc(&vp->d_vreg, vreg_bytes) != hipSuccess) return bail("hipMalloc(vreg)");
+  if (hipMalloc(&vp->d_scratch, (size_t)8 << vp->max_logn) != hipSuccess) return bail("hipMalloc(scratch)");
+  if (hipMalloc(&vp->d_primes, kMaxPrimes * sizeof(PrimeDev)) != hipSuccess) return bail("hipMalloc(primes)");
+  // the RTL's memories power up as X; give them a defined 0 instead
+  if (hipMemsetAsync(vp->d_spm, 0, (vp->spm_rows ? vp->spm_rows : 1) * (size_t)ALOHA_ROW_BYTES, vp->stream) != hipSuccess) return bail("memset");
+  if (hipMemsetAsync(vp->d_ksk, 0, (vp->ksk_rows ? vp->ksk_rows : 1) * (size_t)ALOHA_ROW_BYTES, vp->stream) != hipSuccess) return bail("memset");
+  if (hipMemsetAsync(vp->d_vreg, 0, vreg_bytes, vp->stream) != hipSuccess) return bail("memset");
+  if (hipStreamSynchronize(vp->stream) != hipSuccess) return bail("sync");
+  *out = vp;
+  return ALOHA_OK;
+}
+
+void aloha_vp_destroy(aloha_vp *vp) {
+  if (!vp) return;
+  if (vp->stream) (void)hipStreamSynchronize(vp->stream);
+  for (auto &s : vp->slots) if (s.d_tables) (void)hipFree(s.d_tables);
+  if (vp->d_spm) (void)hipFree(vp->d_spm);
+  if (vp->d_ksk) (void)hipFree(vp->d_ksk);
+  if (vp->d_vreg) (void)hipFree(vp->d_vreg);
+  if (vp->d_scratch) (void)hipFree(vp->d_scratch);
+  if (vp->d_primes) (void)hipFree(vp->d_primes);
+  if (vp->d_jobs) (void)hipFree(vp->d_jobs);
+  if (vp->d_tiles) (void)hipFree(vp->d_tiles);
+  if (vp->own_stream && vp->stream) (void)hipStreamDestroy(vp->stream);
+  delete vp;
+}
+
+static u64 *space_ptr(aloha_vp *vp, int space, uint64_t row, uint64_t bytes) {
+  if (space != ALOHA_SPACE_SPM && space != ALOHA_SPACE_KSK) return nullptr;
+  const uint64_t rows = space == ALOHA_SPACE_SPM ? vp->spm_rows : vp->ksk_rows;
+  if (row > rows || bytes > (rows - row) * (uint64_t)ALOHA_ROW_BYTES) return nullptr;
+  return (space == ALOHA_SPACE_SPM ? vp->d_spm : vp->d_ksk) + row * kLanes;
+}
+
+aloha_status aloha_vp_write(aloha_vp *vp, int space, uint64_t row, const void *src, uint64_t bytes) {
+  if (!vp || !src) return ALOHA_ERR_ARG;
+  u64 *p = space_ptr(vp, space, row, bytes);
+  if (!p) return fail(vp, ALOHA_ERR_ADDR, "write: rows [%llu, +%llu B) outside space %d", (u64)row, (u64)bytes, space);
+  HIPCK(vp, hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));      // host pointer is borrowed for the call only
+  return ALOHA_OK;
+}
+
+aloha_status aloha_vp_read(aloha_vp *vp, int space, uint64_t row, void *dst, uint64_t bytes) {
+  if (!vp || !dst) return ALOHA_ERR_ARG;
+  u64 *p = space_ptr(vp, space, row, bytes);
+  if (!p) return fail(vp, ALOHA_ERR_ADDR, "read: rows [%llu, +%llu B) outside space %d", (u64)row, (u64)bytes, space);
+  HIPCK(vp, hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  return ALOHA_OK;
+}
+
+void *aloha_vp_device_ptr(aloha_vp *vp, int space, uint64_t row) {
+  return vp ? space_ptr(vp, space, row, 0) : nullptr;
+}
+
+aloha_status aloha_vp_load_isram(aloha_vp *vp, uint32_t base_pc, const uint32_t *words, uint32_t n) {
+  if (!vp || !words) return ALOHA_ERR_ARG;
+  if (base_pc > ALOHA_IRAM_DEPTH || n > ALOHA_IRAM_DEPTH - base_pc) return fail(vp, ALOHA_ERR_ADDR, "isram [%u, +%u) outside the %u-word ROM", base_pc, n, ALOHA_IRAM_DEPTH);
+  for (uint32_t i = 0; i < n; i++) {
+    vp->inst[base_pc + i] = words[3 * i];
+    vp->imm[base_pc + i] = ((uint64_t)words[3 * i + 1] << 32) | words[3 * i + 2];
+  }
+  return ALOHA_OK;
+}
+
+aloha_status aloha_vp_load_isram_hex(aloha_vp *vp, uint32_t base_pc, const char *text) {
+  if (!vp || !text) return ALOHA_ERR_ARG;
+  // $readmemh subset: whitespace-separated hex words of up to 24 digits, // comments, '_' separators
+  std::vector<uint32_t> words;
+  const char *p = text;
+  while (*p) {
+    if (p[0] == '/' && p[1] == '/') { while (*p && *p != '\n') p++; continue; }
+    if (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') { p++; continue; }
+    unsigned __int128 v = 0;
+    int digits = 0;
+    while (*p && *p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') {
+      const char c = *p++;
+      if (c == '_') continue;
+      int d;
+      if (c >= '0' && c <= '9') d = c - '0';
+      else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+      else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+      else return fail(vp, ALOHA_ERR_ARG, "isram text: bad character '%c'", c);
+      if (++digits > 24) return fail(vp, ALOHA_ERR_ARG, "isram text: word wider than 96 bit");
+      v = (v << 4) | (unsigned)d;
+    }
+    words.push_back((uint32_t)(v >> 64));
+    words.push_back((uint32_t)(v >> 32));
+    words.push_back((uint32_t)v);
+  }
+  return aloha_vp_load_isram(vp, base_pc, words.data(), (uint32_t)(words.size() / 3));
+}
+
+aloha_status aloha_vp_sync(aloha_vp *vp) {
+  if (!vp) return ALOHA_ERR_ARG;
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  return ALOHA_OK;
+}
+
+aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row, uint64_t rslt_row,
+                          uint64_t ksk_row, uint64_t step) {
+  if (!vp) return ALOHA_ERR_ARG;
+  const uint64_t csr[4] = {src0_row, src1_row, rslt_row, ksk_row};
+  hipStream_t st = vp->stream;
+  for (;; pc++) {
+    if (pc >= ALOHA_IRAM_DEPTH) return fail(vp, ALOHA_ERR_NOBREAK, "no break before the end of the ROM");
+    // field split: expander.v:123-130
+    const uint32_t inst = vp->inst[pc];
+    const uint64_t imm = vp->imm[pc];
+    const unsigned funct6 = inst >> 26, vs2 = (inst >> 20) & 31, vs1 = (inst >> 15) & 31;
+    const unsigned funct3 = (inst >> 12) & 7, vd = (inst >> 7) & 31;
+    vp->stats.instructions++;
+    const bool is_vec = !(funct6 == 0x04 || funct6 == 0x08 || funct6 == 0x0c || funct6 == 0x10 || funct6 == 0x00);
+    unsigned logn = 0;
+    uint32_t n = 0;
+    const uint64_t q = vp->q;
+    if (is_vec) {
+      aloha_status s = vl_logn(vp->vl_bits, vp->max_logn, &logn);
+      if (s) return fail(vp, s, "pc %u: VL = %llu bits", pc, (u64)vp->vl_bits);
+      n = 1u << logn;
+      if (funct6 != 0x03 && funct6 != 0x07 && funct6 != 0x19 && !(q > (1ull << 59) && q < (1ull << 60)))
+        return fail(vp, ALOHA_ERR_MODULUS, "pc %u: arithmetic with q = %#llx", pc, (u64)q);
+    }
+    switch (funct6) {
+      case 0x10: return ALOHA_OK;                                  // break   expander.v:141-151
+      case 0x00: break;                                            // nop
+      case 0x04: {                                                 // vsetvl  :156-159
+        unsigned l;
+        aloha_status s = vl_logn(imm, vp->max_logn, &l);
+        if (s) return fail(vp, s, "pc %u: vsetvl %#llx", pc, (u64)imm);
+        vp->vl_bits = imm;
+        break;
+      }
+      case 0x08:                                                   // vsetq   :160-163
+        if (!modulus_ok(imm)) return fail(vp, ALOHA_ERR_MODULUS, "pc %u: vsetq %#llx", pc, (u64)imm);
+        vp->q = imm;
+        break;
+      case 0x0c: vp->mu = imm; break;                              // vsetiq  :164-167 (RTL Barrett constant; unused here)
+      case 0x01: case 0x05: case 0x09: {                           // vfqmul / vfqadd / vfqsub  :178-373
+        aloha::k::EwOp op;
+        const u64 *a, *b = nullptr;
+        uint64_t s = 0;
+        if (funct3 == 0) {
+          if (((vs1 ^ vs2) & 1) == 0) return fail(vp, ALOHA_ERR_BANK, "pc %u: .vv with v%u, v%u in one bank", pc, vs1, vs2);
+          a = vreg(vp, vs1); b = vreg(vp, vs2);
+          op = funct6 == 0x01 ? aloha::k::EW_MUL_VV : funct6 == 0x05 ? aloha::k::EW_ADD_VV : aloha::k::EW_SUB_VV;
+        } else if (funct3 == 1) {
+          a = vreg(vp, vs1); s = imm;
+          op = funct6 == 0x01 ? aloha::k::EW_MUL_VS : funct6 == 0x05 ? aloha::k::EW_ADD_VS : aloha::k::EW_SUB_VS;
+        } else if (funct3 == 2 && funct6 == 0x09) {
+          a = vreg(vp, vs2); s = imm; op = aloha::k::EW_SUB_SV;
+        } else return fail(vp, ALOHA_ERR_DECODE, "pc %u: funct3 %u on funct6 %#x", pc, funct3, funct6);
+        s = s >= q ? s - q : s;                                    // the scalar is normalised like a lane input (modalu.sv:46)
+        if (s >= q) return fail(vp, ALOHA_ERR_ARG, "pc %u: scalar operand %#llx >= 2q", pc, (u64)imm);
+        HIPCK(vp, aloha::k::ew(st, op, vreg(vp, vd), a, b, s, aloha::nt::shoup(s, q), modctx(q), n));
+        vp->stats.kernel_launches++;
+        break;
+      }
+      case 0x0d: case 0x11:                                        // vfqmod :374-395, vcp :396-417
+        HIPCK(vp, aloha::k::ew(st, funct6 == 0x0d ? aloha::k::EW_MOD : aloha::k::EW_CP, vreg(vp, vd), vreg(vp, vs1),
+                               nullptr, 0, 0, modctx(q), n));
+        vp->stats.kernel_launches++;
+        break;
+      case 0x15: case 0x19: {                                      // vaut / vroli  :460-501,:549-558
+        const uint64_t k = (step + imm) & (n - 1);                 // scalar_iconn = csr_step + imm, kept mod N
+                                                                   // (vxu_lane.sv:594, vxu_top_tb.sv:603)
+        u64 *dst = vreg(vp, vd);
+        const bool inplace = vd == vs1;
+        u64 *out = inplace ? vp->d_scratch : dst;
+        if (funct6 == 0x15) {
+          if (!((step + imm) & 1)) return fail(vp, ALOHA_ERR_AUT, "pc %u: vaut with even exponent %llu", pc, (u64)(step + imm));
+          uint64_t kinv = 1;                                       // k^-1 mod N by Newton iteration (k odd)
+          for (int it = 0; it < 5; it++) kinv = kinv * (2 - k * kinv);
+          kinv &= (n - 1);
+          HIPCK(vp, aloha::k::vaut(st, out, vreg(vp, vs1), logn, q, k, kinv));
+        } else {
+          HIPCK(vp, aloha::k::vroli(st, out, vreg(vp, vs1), logn, k));
+        }
+        vp->stats.kernel_launches++;
+        if (inplace) HIPCK(vp, hipMemcpyAsync(dst, out, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        break;
+      }
+      case 0x02: case 0x06: {                                      // vntt / vintt  :418-459
+        uint32_t slot;
+        aloha_status s = get_slot(vp, q, logn, &slot);
+        if (s) return s;
+        // The RTL ping-pongs between vs1 and vd once per stage (ntt_fsm.sv:80, vxu_lane.sv:315-318):
+        // vs1 is UNDEFINED afterwards; here it is simply left untouched.
+        std::vector<LimbJob> job(1);
+        job[0] = LimbJob{vreg(vp, vs1), vreg(vp, vd), slot, 0};
+        s = run_transforms(vp, job, logn, funct6 == 0x06);
+        if (s) return s;
+        break;
+      }
+      case 0x03: {                                                 // vle  :647-661,:681-686
+        u64 *p = mem_rows(vp, imm, true, csr, n / kLanes);
+        if (!p) return fail(vp, ALOHA_ERR_ADDR, "pc %u: vle imm %#llx out of range", pc, (u64)imm);
+        HIPCK(vp, hipMemcpyAsync(vreg(vp, vd), p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        break;
+      }
+      case 0x07: {                                                 // vse (source register = vs1)  :502-523,:687-692
+        u64 *p = mem_rows(vp, imm, false, csr, n / kLanes);
+        if (!p) return fail(vp, ALOHA_ERR_ADDR, "pc %u: vse imm %#llx out of range", pc, (u64)imm);
+        HIPCK(vp, hipMemcpyAsync(p, vreg(vp, vs1), (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        break;
+      }
+      default:                                                     // RTL: silent no-op bundle (:524-532)
+        return fail(vp, ALOHA_ERR_DECODE, "pc %u: undefined funct6 %#x", pc, funct6);
+    }
+  }
+}
+
+aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64_t src_row, uint32_t log_n,
+                               const uint64_t *moduli, uint32_t count, int inverse) {
+  if (!vp || !moduli) return ALOHA_ERR_ARG;
+  if (log_n < 10 || log_n > 16) return fail(vp, ALOHA_ERR_VL, "ntt_rows: log_n = %u", log_n);
+  const uint64_t rows_per_limb = (1ull << log_n) / kLanes;
+  const uint64_t bytes = (uint64_t)count * rows_per_limb * ALOHA_ROW_BYTES;
+  u64 *src = space_ptr(vp, space, src_row, bytes), *dst = space_ptr(vp, space, dst_row, bytes);
+  if (!src || !dst) return fail(vp, ALOHA_ERR_ADDR, "ntt_rows: %u limbs at rows %llu/%llu outside space %d", count, (u64)src_row, (u64)dst_row, space);
+  std::vector<LimbJob> jobs(count);
+  uint64_t last_q = 0;
+  uint32_t last_slot = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    if (moduli[i] != last_q) {
+      if (!modulus_ok(moduli[i])) return fail(vp, ALOHA_ERR_MODULUS, "ntt_rows: modulus[%u] = %#llx", i, (u64)moduli[i]);
+      aloha_status s = get_slot(vp, moduli[i], log_n, &last_slot);
+      if (s) return s;
+      last_q = moduli[i];
+    }
+    jobs[i] = LimbJob{src + ((size_t)i << log_n), dst + ((size_t)i << log_n), last_slot, 0};
+  }
+  return run_transforms(vp, jobs, log_n, inverse != 0);
+}
+
+aloha_status aloha_find_psi(uint64_t q, uint32_t log_n, uint64_t *psi) {
+  if (!psi) return ALOHA_ERR_ARG;
+  if (!modulus_ok(q)) return ALOHA_ERR_MODULUS;
+  return aloha::nt::find_psi(q, log_n, psi) ? ALOHA_OK : ALOHA_ERR_ROOT;
+}
+
+uint64_t aloha_nth_prime(uint32_t log_n, uint32_t idx) {
+  if (log_n < 1 || log_n > 16) return 0;
+  return aloha::nt::nth_prime(log_n, idx);
+}
+
+aloha_status aloha_vp_get_stats(const aloha_vp *vp, aloha_vp_stats *out) {
+  if (!vp || !out) return ALOHA_ERR_ARG;
+  *out = vp->stats;
+  return ALOHA_OK;
+}
+
+aloha_status aloha_vp_peek_vreg(aloha_vp *vp, uint32_t reg, uint64_t *dst, uint64_t n) {
+  if (!vp || !dst || reg >= ALOHA_NVREG || n > (1ull << vp->max_logn)) return ALOHA_ERR_ARG;
+  HIPCK(vp, hipMemcpyAsync(dst, vreg(vp, reg), n * 8, hipMemcpyDeviceToHost, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  return ALOHA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+"""ctypes binding of libaloha_vp.so (the C ABI in include/aloha_vp.h).
+
+``VP`` mirrors the reference's VP boundary -- instruction ROM, six CSRs + start/done, two
+row-addressed memories (``src/vp/top/vp_top_full.sv:15-41``; test-bench tasks
+``sim/top/top_noaxilite_tb.sv:372-520``) -- with the same call surface as the test oracle's
+``OracleVP`` so parity tests drive both with identical code.
+
+There is NO CPU fallback: if the HIP library is missing, or no gfx950 device is present,
+construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaloha_vp.so")
+
+SPM, KSK = 0, 1
+ROW_BYTES = 1024
+LANES = 128
+FLAG_NO_FUSION = 1
+FLAG_RADIX2_ONLY = 2
+
+STATUS = ["OK", "ERR_ARG", "ERR_VL", "ERR_MODULUS", "ERR_ROOT", "ERR_DECODE", "ERR_BANK", "ERR_ADDR",
+          "ERR_AUT", "ERR_NOBREAK", "ERR_DEVICE", "ERR_NOMEM"]
+(OK, ERR_ARG, ERR_VL, ERR_MODULUS, ERR_ROOT, ERR_DECODE, ERR_BANK, ERR_ADDR, ERR_AUT, ERR_NOBREAK,
+ ERR_DEVICE, ERR_NOMEM) = range(12)
+
+# every symbol include/aloha_vp.h declares
+EXPORTS = ["aloha_vp_abi_version", "aloha_status_string", "aloha_vp_create", "aloha_vp_destroy",
+           "aloha_vp_last_error", "aloha_vp_write", "aloha_vp_read", "aloha_vp_device_ptr",
+           "aloha_vp_load_isram", "aloha_vp_load_isram_hex", "aloha_vp_run", "aloha_vp_sync",
+           "aloha_vp_ntt_rows", "aloha_find_psi", "aloha_nth_prime", "aloha_vp_get_stats",
+           "aloha_vp_peek_vreg"]
+
+
+class AlohaError(RuntimeError):
+    def __init__(self, status: int, msg: str = ""):
+        self.status = status
+        name = STATUS[status] if 0 <= status < len(STATUS) else str(status)
+        super().__init__(f"aloha_vp: {name}{': ' + msg if msg else ''}")
+
+
+class _Config(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("spm_rows", C.c_uint64),
+                ("ksk_rows", C.c_uint64), ("max_log_n", C.c_uint32), ("flags", C.c_uint32),
+                ("stream", C.c_void_p)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("instructions", C.c_uint64), ("kernel_launches", C.c_uint64), ("twiddle_builds", C.c_uint64)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """Load libaloha_vp.so.  torch is imported first so that the process holds exactly one HIP
+    runtime (torch bundles a libamdhip64.so.7 of its own; whichever is loaded first serves both)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AlohaError(ERR_DEVICE, f"{LIB_PATH} is missing -- run `python -m aloha_amd.build` "
+                                     "(the engine has no CPU fallback)")
+    try:
+        import torch  # noqa: F401  (load order matters, see docstring)
+    except Exception:  # torch is plumbing, not a dependency of the library itself
+        pass
+    L = C.CDLL(LIB_PATH)
+    u64, u32, p, i = C.c_uint64, C.c_uint32, C.c_void_p, C.c_int
+    L.aloha_vp_abi_version.restype = u32
+    L.aloha_status_string.restype = C.c_char_p; L.aloha_status_string.argtypes = [i]
+    L.aloha_vp_create.restype = i; L.aloha_vp_create.argtypes = [C.POINTER(_Config), C.POINTER(p)]
+    L.aloha_vp_destroy.restype = None; L.aloha_vp_destroy.argtypes = [p]
+    L.aloha_vp_last_error.restype = C.c_char_p; L.aloha_vp_last_error.argtypes = [p]
+    L.aloha_vp_write.restype = i; L.aloha_vp_write.argtypes = [p, i, u64, p, u64]
+    L.aloha_vp_read.restype = i; L.aloha_vp_read.argtypes = [p, i, u64, p, u64]
+    L.aloha_vp_device_ptr.restype = p; L.aloha_vp_device_ptr.argtypes = [p, i, u64]
+    L.aloha_vp_load_isram.restype = i; L.aloha_vp_load_isram.argtypes = [p, u32, p, u32]
+    L.aloha_vp_load_isram_hex.restype = i; L.aloha_vp_load_isram_hex.argtypes = [p, u32, C.c_char_p]
+    L.aloha_vp_run.restype = i; L.aloha_vp_run.argtypes = [p, u32, u64, u64, u64, u64, u64]
+    L.aloha_vp_sync.restype = i; L.aloha_vp_sync.argtypes = [p]
+    L.aloha_vp_ntt_rows.restype = i; L.aloha_vp_ntt_rows.argtypes = [p, i, u64, u64, u32, p, u32, i]
+    L.aloha_find_psi.restype = i; L.aloha_find_psi.argtypes = [u64, u32, C.POINTER(u64)]
+    L.aloha_nth_prime.restype = u64; L.aloha_nth_prime.argtypes = [u32, u32]
+    L.aloha_vp_get_stats.restype = i; L.aloha_vp_get_stats.argtypes = [p, C.POINTER(_Stats)]
+    L.aloha_vp_peek_vreg.restype = i; L.aloha_vp_peek_vreg.argtypes = [p, u32, p, u64]
+    _lib = L
+    return L
+
+
+def find_psi(q: int, log_n: int) -> int:
+    out = C.c_uint64()
+    rc = load_library().aloha_find_psi(q, log_n, C.byref(out))
+    if rc:
+        raise AlohaError(rc)
+    return int(out.value)
+
+
+def nth_prime(log_n: int, idx: int) -> int:
+    return int(load_library().aloha_nth_prime(log_n, idx))
+
+
+class VP:
+    """One VP engine on one GPU (one process per GPU; handles are single-threaded)."""
+
+    def __init__(self, spm_rows: int = 1 << 16, ksk_rows: int = 1 << 16, max_log_n: int = 16,
+                 device: int = 0, flags: int = 0, stream: int = 0):
+        L = load_library()
+        cfg = _Config(abi_version=L.aloha_vp_abi_version(), device=device, spm_rows=spm_rows,
+                      ksk_rows=ksk_rows, max_log_n=max_log_n, flags=flags, stream=stream or None)
+        h = C.c_void_p()
+        rc = L.aloha_vp_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise AlohaError(rc, "aloha_vp_create failed (needs a gfx950 device; there is no CPU path)")
+        self._h = h
+        self._L = L
+        self.spm_rows, self.ksk_rows = spm_rows, ksk_rows
+
+    # -- lifecycle --------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.aloha_vp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def last_error(self) -> str:
+        return self._L.aloha_vp_last_error(self._h).decode()
+
+    def _chk(self, rc: int) -> None:
+        if rc:
+            raise AlohaError(rc, self.last_error)
+
+    # -- memory -----------------------------------------------------------------------------
+    def write(self, space: int, row: int, data) -> None:
+        a = np.ascontiguousarray(data, dtype=np.uint64)
+        self._chk(self._L.aloha_vp_write(self._h, space, row, a.ctypes.data, a.nbytes))
+
+    def read(self, space: int, row: int, nwords: int) -> np.ndarray:
+        out = np.empty(nwords, dtype=np.uint64)
+        self._chk(self._L.aloha_vp_read(self._h, space, row, out.ctypes.data, out.nbytes))
+        return out
+
+    def device_ptr(self, space: int, row: int) -> int:
+        p = self._L.aloha_vp_device_ptr(self._h, space, row)
+        if not p:
+            raise AlohaError(ERR_ADDR, "row outside the space")
+        return int(p)
+
+    # -- program ----------------------------------------------------------------------------
+    def load_isram(self, base_pc: int, words) -> None:
+        w = np.ascontiguousarray(words, dtype=np.uint32).reshape(-1, 3)
+        self._chk(self._L.aloha_vp_load_isram(self._h, base_pc, w.ctypes.data, w.shape[0]))
+
+    def load_isram_hex(self, base_pc: int, text: str) -> None:
+        self._chk(self._L.aloha_vp_load_isram_hex(self._h, base_pc, text.encode()))
+
+    def run(self, pc: int, src0: int = 0, src1: int = 0, rslt: int = 0, ksk: int = 0, step: int = 0) -> int:
+        """Start the program at ``pc`` with the six CSRs; returns the status code (0 = ok)
+        like the oracle's ``run`` so error behaviour can be compared."""
+        return int(self._L.aloha_vp_run(self._h, pc, src0, src1, rslt, ksk, step))
+
+    def sync(self) -> None:
+        self._chk(self._L.aloha_vp_sync(self._h))
+
+    # -- batched transforms -------------------------------------------------------------------
+    def ntt_rows(self, space: int, dst_row: int, src_row: int, log_n: int, moduli: Sequence[int],
+                 inverse: bool = False) -> None:
+        m = np.ascontiguousarray(moduli, dtype=np.uint64)
+        self._chk(self._L.aloha_vp_ntt_rows(self._h, space, dst_row, src_row, log_n, m.ctypes.data,
+                                            m.size, int(bool(inverse))))
+
+    # -- introspection ------------------------------------------------------------------------
+    def stats(self) -> dict:
+        s = _Stats()
+        self._chk(self._L.aloha_vp_get_stats(self._h, C.byref(s)))
+        return {"instructions": int(s.instructions), "kernel_launches": int(s.kernel_launches),
+                "twiddle_builds": int(s.twiddle_builds)}
+
+    def peek_vreg(self, reg: int, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.uint64)
+        self._chk(self._L.aloha_vp_peek_vreg(self._h, reg, out.ctypes.data, n))
+        return out

@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: forward negacyclic NTT/s at N = 2^16, 60-bit primes.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--primes L] [--polys P]
+
+One "step" = one pass of the hot path (vntt, fused over the batch: aloha_vp_ntt_rows) over a
+batch of L x P limbs of N = 2^16 coefficients resident in HBM, in place.  The default batch
+(32 primes x 32 limbs = 1024 limbs = 512 MiB) is twice the 256 MiB Infinity Cache, so every
+step streams from HBM.  For N > 1 the driver launches one rank per GPU (torch.distributed,
+backend nccl = RCCL); limbs are independent so ranks share nothing on the data path (weak
+scaling: every rank transforms its own batch), only the barrier and the max-over-ranks of the
+elapsed time go through the collective.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- algorithmic bytes (16*N per transform) / measured device time of
+                  the transform's kernels, against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (oracle/vp_oracle.c, a scalar port of the reference's
+                  arithmetic; the reference itself is RTL and cannot run here) timed on this
+                  host for a bounded sample of the same transforms.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+LOGN = 16
+N = 1 << LOGN
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(seconds: float = 10.0) -> dict:
+    import oracle
+    q = oracle.nth_prime(LOGN, 0)
+    rng = np.random.default_rng(1)
+    batch = 16
+    a = rng.integers(0, q, size=(batch, N), dtype=np.uint64)
+    oracle.ntt(a[:1], q)                                   # warm (library load, page-in)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        oracle.ntt(a, q)
+        done += batch
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "NTT/s", "cores": 1, "kind": "port",
+            "sample": f"{done} forward NTTs, N=2^16, one 60-bit prime, single thread, "
+                      f"{dt:.1f} s on {os.cpu_count()} host cores available"}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--primes", type=int, default=32)
+    ap.add_argument("--polys", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the engine has no CPU path", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from aloha_amd import vp as avp
+
+    L, P = args.primes, args.polys
+    B = L * P
+    rows_per_limb = N // 128
+    stream = torch.cuda.Stream()
+    vp = avp.VP(spm_rows=B * rows_per_limb, ksk_rows=1, max_log_n=LOGN, device=local_rank,
+                stream=stream.cuda_stream)
+    primes = [avp.nth_prime(LOGN, i) for i in range(L)]
+    moduli = [q for q in primes for _ in range(P)]
+    rng = np.random.default_rng(0xA10A + rank)
+    for i, q in enumerate(primes):                          # synthetic canonical residues, prime by prime
+        blk = rng.integers(0, q, size=P * N, dtype=np.uint64)
+        vp.write(avp.SPM, i * P * rows_per_limb, blk)
+        if i == 0:
+            first_in = blk[:N].copy()
+    # correctness guard inside the bench: the first limb of the first step against the oracle
+    vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli)
+    vp.sync()
+    if rank == 0:
+        import oracle
+        got = vp.read(avp.SPM, 0, N)
+        if not np.array_equal(got, oracle.ntt(first_in, primes[0])):
+            print("bench.py: GPU result differs from the oracle", file=sys.stderr)
+            return 3
+    for _ in range(max(0, args.warmup - 1)):
+        vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli)
+    vp.sync()
+    launches0 = vp.stats()["kernel_launches"]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        ev0.record(stream)
+        for _ in range(args.steps):
+            vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli)
+        ev1.record(stream)
+    vp.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    dev_ms = ev0.elapsed_time(ev1)                          # device time of the K steps on the engine's stream
+    launches = vp.stats()["kernel_launches"] - launches0
+    if dist is not None:
+        t = torch.tensor([elapsed, dev_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        total_ntts = world * B * args.steps
+        alg_bytes_step = 16 * N * B                         # read N + write N words per transform
+        dev_s_step = dev_ms / 1e3 / args.steps
+        achieved = alg_bytes_step / dev_s_step / 1e9
+        out = {
+            "metric": "fwd-NTT/s at N=2^16, 60-bit prime", "value": total_ntts / elapsed, "unit": "NTT/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"forward negacyclic NTT (vntt), N=2^16, batch of {B} limbs per GPU "
+                                   f"({L} 60-bit primes x {P} limbs), in place in HBM ({B * N * 8 >> 20} MiB)",
+                       "log_n": LOGN, "limbs_per_gpu": B, "primes": L, "limbs_per_prime": P,
+                       "kernels_per_step": launches // max(1, args.steps)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "achieved = 16*N*B algorithmic bytes / device time of one step (both "
+                                 "tile kernels, HIP events on the engine's stream); ALU-bound regime: "
+                                 "see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    vp.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,130 @@
+/*
+ * include/aloha_vp.h -- C ABI of libaloha_vp.so: the ALOHA vector processor (VP) lane
+ * datapath on MI355X (gfx950).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * This is the drop-in boundary for the reference's hot path.  In the reference the VP is
+ * driven through module ports / test-bench tasks (there is no software driver):
+ *
+ *   reference interface (relative to AntChainOpenLabs/ALOHA)          replaced by
+ *   ---------------------------------------------------------------    --------------------
+ *   vp_top_full ports  src/vp/top/vp_top_full.sv:15-41                 aloha_vp_create/destroy
+ *   inst_rom $readmemh image  src/vp/sequncer/inst_rom.v:32-35         aloha_vp_load_isram[_hex]
+ *   CSR pins pc/src0/src1/rslt/ksk/step + start/done
+ *     src/top/h2_top_no_axilite.sv:60-79,:145-157;
+ *     TB task run_vp  sim/top/top_noaxilite_tb.sv:396-417             aloha_vp_run / aloha_vp_sync
+ *   DMA <-> SPM / KSK memory  run_load_cipher/run_store_cipher/
+ *     copy_spm_to_dram/load_ksk  top_noaxilite_tb.sv:372-394,:450-520  aloha_vp_write / aloha_vp_read
+ *   instruction semantics  src/vp/sequncer/expander.v:65-700           (executed inside run)
+ *
+ * Memory model: two row-addressed spaces, rows of 128 x u64 = 1024 bytes in
+ * plain little-endian linear order (src/mem_buf/spm.sv:118-126, ksk_mem.sv:46-54).  A
+ * polynomial limb of N coefficients occupies N/128 consecutive rows, coefficient i at byte
+ * 8*i.  All residues are canonical or at least < 2^60 (< 2q): the RTL's ALU normalises its
+ * inputs with ONE conditional subtraction (src/vp/vxu/modalu.sv:44-46).
+ *
+ * Errors: the RTL signals nothing and leaves bad encodings undefined (unknown funct6 is a
+ * silent no-op bundle, expander.v:524-532).  This library instead returns a status and
+ * REJECTS what the RTL leaves undefined.  Threading: a handle is single-threaded, like the
+ * one-instruction-in-flight sequencer (seq_top.v:343-413); internally work is enqueued on a
+ * HIP stream, aloha_vp_run may return before completion, aloha_vp_sync / aloha_vp_read block.
+ */
+#ifndef ALOHA_VP_H
+#define ALOHA_VP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALOHA_VP_ABI_VERSION 1
+
+typedef enum {
+  ALOHA_OK = 0,
+  ALOHA_ERR_ARG = 1,      /* null / out-of-range argument                                  */
+  ALOHA_ERR_VL = 2,       /* VL != 64 * 2^k, k in [10,16]   (ntt_fsm.sv:59-65)              */
+  ALOHA_ERR_MODULUS = 3,  /* q not a prime in (2^59, 2^60)  (mod width hard-wired to 60,
+                             vxu_lane.sv:539)                                               */
+  ALOHA_ERR_ROOT = 4,     /* q != 1 mod 2N at vntt/vintt: no 2N-th root of unity            */
+  ALOHA_ERR_DECODE = 5,   /* unknown funct6 / funct3        (expander.v:524-532)            */
+  ALOHA_ERR_BANK = 6,     /* .vv operands in the same register bank (expander.v:183-200)    */
+  ALOHA_ERR_ADDR = 7,     /* memory row range outside the configured space                  */
+  ALOHA_ERR_AUT = 8,      /* even automorphism exponent (not a permutation)                 */
+  ALOHA_ERR_NOBREAK = 9,  /* ran off the instruction ROM without `break`                    */
+  ALOHA_ERR_DEVICE = 10,  /* HIP runtime error / no gfx950 device (never a CPU fallback)    */
+  ALOHA_ERR_NOMEM = 11
+} aloha_status;
+
+enum { ALOHA_SPACE_SPM = 0, ALOHA_SPACE_KSK = 1 };
+#define ALOHA_ROW_BYTES 1024u   /* 128 lanes x 8 B: vp_defines.vh:25,:62 */
+#define ALOHA_IRAM_DEPTH 4096u  /* vp_defines.vh:31 */
+#define ALOHA_NVREG 32u
+
+typedef struct aloha_vp aloha_vp;
+
+typedef struct {
+  uint32_t abi_version;   /* ALOHA_VP_ABI_VERSION                                            */
+  int32_t device;         /* HIP device ordinal                                              */
+  uint64_t spm_rows;      /* rows in the scratch-pad space (reference: 2^16, spm.sv:12-21)   */
+  uint64_t ksk_rows;      /* rows in the key-switch-key space (ksk_mem.sv:12-21)             */
+  uint32_t max_log_n;     /* largest ring size the register file is sized for (10..16)       */
+  uint32_t flags;         /* ALOHA_FLAG_*                                                    */
+  void *stream;           /* hipStream_t to enqueue on, or NULL for a private stream         */
+} aloha_vp_config;
+
+#define ALOHA_FLAG_NO_FUSION 1u    /* one kernel per instruction (debug / parity bisecting)  */
+#define ALOHA_FLAG_RADIX2_ONLY 2u /* transforms by radix-2 stage launches only (cross-check) */
+
+/* ---- lifecycle ----------------------------------------------------------------------- */
+aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out);
+void aloha_vp_destroy(aloha_vp *vp);
+const char *aloha_vp_last_error(const aloha_vp *vp);      /* text of the last failure      */
+const char *aloha_status_string(aloha_status s);
+uint32_t aloha_vp_abi_version(void);
+
+/* ---- memory (replaces the AXI DMA paths) ------------------------------------------------ */
+aloha_status aloha_vp_write(aloha_vp *vp, int space, uint64_t row, const void *host_src, uint64_t bytes);
+aloha_status aloha_vp_read(aloha_vp *vp, int space, uint64_t row, void *host_dst, uint64_t bytes);
+/* device address of a row, for callers that fill/consume HBM directly (zero copy) */
+void *aloha_vp_device_ptr(aloha_vp *vp, int space, uint64_t row);
+
+/* ---- instruction ROM ---------------------------------------------------------------------- */
+/* n words of {inst32, imm[63:32], imm[31:0]} placed at ROM address base_pc */
+aloha_status aloha_vp_load_isram(aloha_vp *vp, uint32_t base_pc, const uint32_t *words, uint32_t n);
+/* the reference's $readmemh text, one 24-hex-digit word per line, loaded unchanged */
+aloha_status aloha_vp_load_isram_hex(aloha_vp *vp, uint32_t base_pc, const char *text);
+
+/* ---- run: the six CSRs + start (top_noaxilite_tb.sv:396-417) -------------------------------- */
+aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
+                          uint64_t rslt_row, uint64_t ksk_row, uint64_t rot_step);
+aloha_status aloha_vp_sync(aloha_vp *vp);   /* `done` */
+
+/* ---- batched transforms on rows (the fused form of N x {vsetq; vle; vntt|vintt; vse}) ---------
+ * count limbs of 2^log_n coefficients; limb i is read at src_row + i*(N/128) and written at
+ * dst_row + i*(N/128) (src_row == dst_row allowed), under modulus moduli[i].  Identical
+ * results to running the encode_post-style program (encode_post.mem:1-12) limb by limb. */
+aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64_t src_row,
+                               uint32_t log_n, const uint64_t *moduli, uint32_t count, int inverse);
+
+/* ---- parameters ------------------------------------------------------------------------------ */
+/* minimal primitive 2N-th root of unity mod q -- the rule behind the reference's hard-coded
+ * psi values (tf_rom_generator.sv:75) */
+aloha_status aloha_find_psi(uint64_t q, uint32_t log_n, uint64_t *psi);
+/* idx-th largest prime p < 2^60 with p == 1 (mod 2^(log_n+1)) */
+uint64_t aloha_nth_prime(uint32_t log_n, uint32_t idx);
+
+/* ---- introspection ------------------------------------------------------------------------- */
+typedef struct {
+  uint64_t instructions;    /* instructions retired since create                             */
+  uint64_t kernel_launches; /* HIP kernel launches issued                                    */
+  uint64_t twiddle_builds;  /* (q, N) twiddle tables generated                               */
+} aloha_vp_stats;
+aloha_status aloha_vp_get_stats(const aloha_vp *vp, aloha_vp_stats *out);
+/* copy a vector register to the host (debug; not architecturally visible in the reference) */
+aloha_status aloha_vp_peek_vreg(aloha_vp *vp, uint32_t reg, uint64_t *host_dst, uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALOHA_VP_H */

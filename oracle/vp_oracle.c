@@ -436,6 +436,7 @@ int orc_vp_run(orc_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
         } else if (funct3 == 2 && funct6 == 0x09) {               /* vfqsub.sv: imm - vs2 */
           a = vp->vreg[vs2]; s = imm; op = 0x0a;
         } else return ORC_ERR_DECODE;
+        if (s >= 2 * q) return ORC_ERR_ARG;                       /* scalar outside the ALU's domain */
         uint64_t *d = vp->vreg[vd];
         for (uint64_t i = 0; i < n; i++) orc_alu(op, a[i], b ? b[i] : 0, s, q, &d[i], NULL);
         break;

@@ -1,0 +1,80 @@
+"""CPU-side checks of the C-ABI library: it builds, loads, exports every symbol the header
+declares, and refuses to run without a GPU (no CPU fallback).  Host-only parameter helpers
+are cross-checked against the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import oracle
+from aloha_amd import build as abuild
+from aloha_amd import vp as avp
+from util import P, Q0, Q1
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    abuild.build()
+    return avp.load_library()
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "aloha_vp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(aloha_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported(lib):
+    names = _declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/aloha_vp.h but not exported"
+    assert sorted(avp.EXPORTS) == names          # the binding covers exactly the header
+
+
+def test_abi_version_and_status_strings(lib):
+    assert lib.aloha_vp_abi_version() == 1
+    for s in range(12):
+        assert lib.aloha_status_string(s)
+    assert lib.aloha_status_string(0) == b"ok"
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(avp.AlohaError) as e:
+        avp.VP(spm_rows=64, ksk_rows=64)
+    assert e.value.status == avp.ERR_DEVICE
+
+
+def test_create_rejects_bad_config(lib):
+    h = ctypes.c_void_p()
+    cfg = avp._Config(abi_version=99, device=0, spm_rows=1, ksk_rows=1, max_log_n=13, flags=0, stream=None)
+    assert lib.aloha_vp_create(ctypes.byref(cfg), ctypes.byref(h)) == avp.ERR_ARG
+    cfg = avp._Config(abi_version=1, device=0, spm_rows=1, ksk_rows=1, max_log_n=17, flags=0, stream=None)
+    assert lib.aloha_vp_create(ctypes.byref(cfg), ctypes.byref(h)) == avp.ERR_ARG
+    assert lib.aloha_vp_create(None, ctypes.byref(h)) == avp.ERR_ARG
+
+
+def test_host_parameter_helpers_match_oracle(lib):
+    # the reference's hard-coded roots (tf_rom_generator.sv:75)
+    assert avp.find_psi(Q0, 13) == 3825716582911
+    assert avp.find_psi(Q1, 13) == 79932510954937
+    assert avp.find_psi(P, 13) == 101017252977188
+    for logn in (10, 12, 16):
+        for idx in (0, 1, 5):
+            p = avp.nth_prime(logn, idx)
+            assert p == oracle.nth_prime(logn, idx)
+            assert oracle.is_prime(p) and p % (2 << logn) == 1 and (1 << 59) < p < (1 << 60)
+        q = avp.nth_prime(logn, 2)
+        assert avp.find_psi(q, logn) == oracle.find_psi(q, logn)
+    with pytest.raises(avp.AlohaError) as e:
+        avp.find_psi(P, 14)                      # P - 1 has 2-adic valuation 14 < 15
+    assert e.value.status == avp.ERR_ROOT
+    with pytest.raises(avp.AlohaError) as e:
+        avp.find_psi(Q0 + 2, 13)
+    assert e.value.status == avp.ERR_MODULUS

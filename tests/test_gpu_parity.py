@@ -1,0 +1,310 @@
+"""GPU parity tests: the HIP engine, through the C ABI, against the CPU oracle and the
+reference's golden vectors.  Bit-exact (integer path): every comparison is array equality.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+import oracle
+from aloha_amd import harness, isa, programs
+from aloha_amd import vp as avp
+from util import N, P, Q0, Q1, load, manifest, reference_images
+from test_oracle_golden import _own_images, check_case0, check_case2, run_case0, run_case2
+
+pytestmark = pytest.mark.gpu
+
+SPM, KSK = 0, 1
+
+
+@pytest.fixture(scope="module")
+def engine():
+    vp = avp.VP(spm_rows=1 << 16, ksk_rows=1 << 16, max_log_n=16)
+    yield vp
+    vp.close()
+
+
+@pytest.fixture(scope="module")
+def engine_radix2():
+    vp = avp.VP(spm_rows=1 << 14, ksk_rows=64, max_log_n=16, flags=avp.FLAG_RADIX2_ONLY)
+    yield vp
+    vp.close()
+
+
+def residues(rng, shape, q, edge=True):
+    a = rng.integers(0, q, size=shape, dtype=np.uint64)
+    if edge:                                      # force the extremes into every limb
+        flat = a.reshape(-1)
+        flat[:4] = [0, 1, q - 1, q - 2]
+        flat[-2:] = [q - 1, 0]
+    return a
+
+
+# ---- golden chains through the C ABI -------------------------------------------------------------
+@pytest.mark.parametrize("which", ["reference_images", "own_programs"])
+def test_case0_chain_on_gpu(engine, which):
+    tb = harness.TestBench(engine)
+    tb.load_programs(reference_images() if which == "reference_images" else _own_images())
+    check_case0(run_case0(engine, tb))
+
+
+def test_case2_chain_29_ops_on_gpu(engine):
+    tb = harness.TestBench(engine)
+    tb.load_programs(reference_images())
+    check_case2(*run_case2(engine, tb))
+
+
+def test_model_kernel_rotate_step4_on_gpu(engine):
+    m = manifest()["case1"]
+    tb = harness.TestBench(engine)
+    tb.load_programs(reference_images())
+    tb.load_ksk([np.zeros(12 * N, np.uint64), load(m["ksk_step4"])])
+    engine.write(SPM, 0, load(m["kernel12_ct_before_rotate"]))
+    tb.run_rotate(0x100, 0x000, 4)
+    assert np.array_equal(tb.copy_spm(0x100), load(m["kernel12_ct_after_rotate"]))
+
+
+def test_isram_hex_text_is_accepted_unchanged(engine):
+    img = reference_images()["mul_plain"]
+    engine.load_isram_hex(64, "// comment line\n" + isa.to_mem_text(img))
+    m = manifest()["case0"]
+    ct, pt = load(m["inst_0_out"]), load(m["inst_2_out"])[:2 * N]
+    engine.write(SPM, 0, ct); engine.write(SPM, 0x200, pt)
+    assert engine.run(64, src0=0, src1=0x200, rslt=0x300) == 0
+    got = engine.read(SPM, 0x300, 4 * N).reshape(2, 2, N)
+    ctr, ptr = ct.reshape(2, 2, N), pt.reshape(2, N)
+    for c in range(2):
+        for j, q in enumerate((Q0, Q1)):
+            exp = (ctr[c, j].astype(object) * ptr[j].astype(object)) % q
+            assert np.array_equal(got[c, j], exp.astype(np.uint64))
+
+
+# ---- transforms vs the oracle ----------------------------------------------------------------------
+def _ntt_case(vp, logn, moduli, polys_per_prime, inverse, rng, inplace=True):
+    n = 1 << logn
+    mods = [q for q in moduli for _ in range(polys_per_prime)]
+    data = np.stack([residues(rng, n, q) for q in mods])
+    rows = n // 128
+    vp.write(SPM, 0, data.reshape(-1))
+    dst = 0 if inplace else len(mods) * rows
+    vp.ntt_rows(SPM, dst, 0, logn, mods, inverse=inverse)
+    got = vp.read(SPM, dst, len(mods) * n).reshape(len(mods), n)
+    for i, q in enumerate(mods):
+        exp = oracle.ntt(data[i], q, inverse=inverse)
+        assert np.array_equal(got[i], exp), f"logn={logn} limb {i} inverse={inverse}"
+    if not inplace:                               # source must be untouched
+        assert np.array_equal(vp.read(SPM, 0, len(mods) * n).reshape(len(mods), n), data)
+
+
+@pytest.mark.parametrize("logn", [10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_ntt_single_limb_all_sizes(engine, logn, inverse):
+    rng = np.random.default_rng(100 + logn)
+    q = oracle.nth_prime(logn, 0) if logn != 13 else Q0
+    _ntt_case(engine, logn, [q], 1, inverse, rng)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_ntt_reference_primes_n8192(engine, inverse):
+    rng = np.random.default_rng(7)
+    _ntt_case(engine, 13, [Q0, Q1, P], 2, inverse, rng)
+
+
+@pytest.mark.parametrize("ppp", [1, 2, 3, 4, 5, 8, 16, 19])
+def test_ntt_n65536_bundles(engine, ppp):
+    """Every bundle shape of the row pass: 16/8/4 limbs per prime (LDS twiddles), 1-2 (global)."""
+    rng = np.random.default_rng(200 + ppp)
+    mods = [oracle.nth_prime(16, i) for i in range(2)]
+    _ntt_case(engine, 16, mods, ppp, False, rng)
+    _ntt_case(engine, 16, mods[:1], ppp, True, rng, inplace=False)
+
+
+def test_ntt_worst_case_ranges(engine):
+    """All-(q-1) and alternating inputs drive the lazy ranges to their bounds."""
+    logn, n = 16, 1 << 16
+    for idx in (0, 7):
+        q = oracle.nth_prime(logn, idx)
+        pats = np.stack([np.full(n, q - 1, np.uint64), np.where(np.arange(n) % 2 == 0, q - 1, 0).astype(np.uint64),
+                         np.zeros(n, np.uint64), np.full(n, (1 << 60) - 1, np.uint64)])   # last: >= q, < 2q
+        engine.write(SPM, 0, pats.reshape(-1))
+        engine.ntt_rows(SPM, 0, 0, logn, [q] * 4)
+        got = engine.read(SPM, 0, 4 * n).reshape(4, n)
+        for i in range(4):
+            src = pats[i] % np.uint64(q)
+            assert np.array_equal(got[i], oracle.ntt(src, q)), f"pattern {i}"
+        engine.ntt_rows(SPM, 0, 0, logn, [q] * 4, inverse=True)
+        back = engine.read(SPM, 0, 4 * n).reshape(4, n)
+        assert np.array_equal(back, pats % np.uint64(q))
+
+
+@pytest.mark.parametrize("logn", [10, 13, 16])
+def test_tile_kernels_agree_with_radix2_fallback(engine, engine_radix2, logn):
+    rng = np.random.default_rng(300 + logn)
+    n = 1 << logn
+    q = oracle.nth_prime(logn, 1)
+    data = residues(rng, (5, n), q)
+    for vp in (engine, engine_radix2):
+        vp.write(SPM, 0, data.reshape(-1))
+    out = []
+    for vp in (engine, engine_radix2):
+        vp.ntt_rows(SPM, 0, 0, logn, [q] * 5)
+        f = vp.read(SPM, 0, 5 * n)
+        vp.ntt_rows(SPM, 0, 0, logn, [q] * 5, inverse=True)
+        out.append((f, vp.read(SPM, 0, 5 * n)))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], data.reshape(-1)) and np.array_equal(out[1][1], data.reshape(-1))
+
+
+def test_ntt_full_batch_properties(engine):
+    """BASELINE-size batch (256 limbs, N = 2^16): spot-check limbs against the oracle and
+    check the size-independent properties on all of them: round trip and linearity."""
+    logn, n, L, PPP = 16, 1 << 16, 16, 16
+    rng = np.random.default_rng(11)
+    mods = [oracle.nth_prime(logn, i) for i in range(L) for _ in range(PPP)]
+    a = np.stack([residues(rng, n, q, edge=False) for q in mods])
+    b = np.stack([residues(rng, n, q, edge=False) for q in mods])
+    s = np.stack([(a[i] + b[i]) % np.uint64(q) for i, q in enumerate(mods)])        # a + b < 2^61: no wrap
+    rows = len(mods) * n // 128
+    vp = avp.VP(spm_rows=3 * rows, ksk_rows=1, max_log_n=16)
+    try:
+        for k, arr in enumerate((a, b, s)):
+            vp.write(SPM, k * rows, arr.reshape(-1))
+            vp.ntt_rows(SPM, k * rows, k * rows, logn, mods)
+        fa, fb, fs = (vp.read(SPM, k * rows, len(mods) * n).reshape(len(mods), n) for k in range(3))
+        for i in (0, 15, 16, 100, 255):
+            assert np.array_equal(fa[i], oracle.ntt(a[i], mods[i]))
+        for i, q in enumerate(mods):               # linearity: NTT(a) + NTT(b) == NTT(a + b)
+            lhs = fa[i] + fb[i]
+            lhs = np.where(lhs >= np.uint64(q), lhs - np.uint64(q), lhs)
+            assert np.array_equal(lhs, fs[i]), f"linearity limb {i}"
+            assert int(fa[i].max()) < q
+        vp.ntt_rows(SPM, 0, 0, logn, mods, inverse=True)
+        assert np.array_equal(vp.read(SPM, 0, len(mods) * n).reshape(len(mods), n), a)
+    finally:
+        vp.close()
+
+
+# ---- element-wise ops, permutations: ISA level -----------------------------------------------------
+def _run_asm(vp, text, **csr):
+    vp.load_isram(1024, isa.assemble(text))
+    return vp.run(1024, **csr)
+
+
+@pytest.mark.parametrize("logn", [10, 13, 16])
+def test_elementwise_isa_ops_match_oracle(engine, logn):
+    n = 1 << logn
+    rows = n // 128
+    rng = np.random.default_rng(400 + logn)
+    q = Q1 if logn == 13 else oracle.nth_prime(logn, 3)
+    a = residues(rng, n, q); b = residues(rng, n, q)
+    a[5], b[5] = (1 << 60) - 1, (1 << 60) - 2          # non-canonical inputs (< 2q) get one conditional subtract
+    s = int(rng.integers(0, q))
+    prog = f"""
+        vsetvl {64 * n:#x}
+        vsetq {q:#x}
+        vle v0, src0+0x0
+        vle v1, src1+0x0
+        vfqmul.vv v2, v0, v1
+        vse v2, rslt+{0 * 8 * n:#x}
+        vfqadd.vv v2, v0, v1
+        vse v2, rslt+{1 * 8 * n:#x}
+        vfqsub.vv v2, v0, v1
+        vse v2, rslt+{2 * 8 * n:#x}
+        vfqsub.vv v3, v1, v0
+        vse v3, rslt+{3 * 8 * n:#x}
+        vfqmul.vs v2, v0, {s:#x}
+        vse v2, rslt+{4 * 8 * n:#x}
+        vfqadd.vs v2, v1, {s:#x}
+        vse v2, rslt+{5 * 8 * n:#x}
+        vfqsub.vs v2, v0, {s:#x}
+        vse v2, rslt+{6 * 8 * n:#x}
+        vfqsub.sv v2, {s:#x}, v1
+        vse v2, rslt+{7 * 8 * n:#x}
+        vfqmod v2, v0
+        vse v2, rslt+{8 * 8 * n:#x}
+        vcp v4, v1
+        vse v4, rslt+{9 * 8 * n:#x}
+        break
+    """
+    o = oracle.OracleVP(spm_rows=16 * rows, ksk_rows=1)
+    results = []
+    for vp in (engine, o):
+        vp.write(SPM, 0, a); vp.write(SPM, rows, b)
+        vp.load_isram(1024, isa.assemble(prog))
+        assert vp.run(1024, src0=0, src1=rows, rslt=2 * rows) == 0
+        vp.sync()
+        results.append(vp.read(SPM, 2 * rows, 10 * n))
+    assert np.array_equal(results[0], results[1])
+    assert int(results[0].max()) < q
+
+
+@pytest.mark.parametrize("logn", [10, 13, 16])
+def test_vaut_vroli_match_oracle(engine, logn):
+    n = 1 << logn
+    rows = n // 128
+    rng = np.random.default_rng(500 + logn)
+    q = Q0 if logn == 13 else oracle.nth_prime(logn, 0)
+    a = residues(rng, n, q)
+    for k in (1, 3, pow(3, 2, 2 * n), pow(3, 8, 2 * n) % n | 1, n - 1, n + 5):
+        prog = f"vsetvl {64 * n:#x}\nvsetq {q:#x}\nvle v0, src0+0x0\nvaut v2, v0, 0x0\nvse v2, rslt+0x0\n" \
+               f"vaut v0, v0, 0x0\nvse v0, rslt+{8 * n:#x}\nvroli v3, v2, {k % 97:#x}\nvse v3, rslt+{16 * n:#x}\nbreak"
+        engine.write(SPM, 0, a)
+        assert _run_asm(engine, prog, src0=0, rslt=rows, step=k) == 0
+        got = engine.read(SPM, rows, 3 * n).reshape(3, n)
+        exp = oracle.vaut(a, q, k)
+        assert np.array_equal(got[0], exp), f"vaut k={k}"
+        assert np.array_equal(got[1], exp), f"in-place vaut k={k}"
+        assert np.array_equal(got[2], oracle.vroli(exp, k % 97))
+
+
+def test_error_codes_match_oracle(engine):
+    progs = [
+        (f"vsetvl 0x80000\nvsetq {Q0:#x}\nvfqadd.vv v2, v0, v4\nbreak", {}),
+        ("vsetvl 0x80001\nbreak", {}),
+        ("vsetvl 0x80000\nvsetq 0x123\nbreak", {}),
+        ("vsetvl 0x80000\nvle v0, src0+0x0\nbreak", {"src0": (1 << 16) - 10}),
+        (f"vsetvl 0x80000\nvsetq {Q0:#x}\nvaut v2, v0, 0x2\nbreak", {}),
+        (f"vsetvl 0x100000\nvsetq {P:#x}\nvle v0, src0+0x0\nvntt v2, v0\nbreak", {}),
+        (f"vsetvl 0x80000\nvsetq {Q0:#x}\nvfqadd.vs v2, v0, {2 * Q0:#x}\nbreak", {}),
+        (f"vsetvl 0x80000\nvsetq {Q0:#x}\nvle v0, src0+0x0\nvcp v2, v0", {}),        # no break
+    ]
+    o = oracle.OracleVP()
+    for text, csr in progs:
+        words = isa.assemble(text)
+        codes = []
+        for vp in (engine, o):
+            vp.load_isram(2048, np.zeros((2048, 3), np.uint32))
+            vp.load_isram(2048, words)
+            codes.append(vp.run(2048, **csr))
+        assert codes[0] == codes[1] and codes[0] != 0, (text, codes)
+    engine.load_isram(2048, np.array([[0xFC00000B, 0, 0]], dtype=np.uint32))
+    assert engine.run(2048) == avp.ERR_DECODE
+
+
+def test_poly_mul_program_config3(engine):
+    """BASELINE config 3: c = iNTT(NTT(a) . NTT(b)), N = 2^14, 8 limbs, via the ISA."""
+    logn, n, L = 14, 1 << 14, 8
+    rows = n // 128
+    mods = [oracle.nth_prime(logn, i) for i in range(L)]
+    rng = np.random.default_rng(33)
+    a = np.stack([residues(rng, n, q) for q in mods]); b = np.stack([residues(rng, n, q) for q in mods])
+    words = programs.assemble(programs.poly_mul(n, mods))
+    o = oracle.OracleVP(spm_rows=3 * L * rows, ksk_rows=1)
+    res = []
+    for vp in (engine, o):
+        vp.write(SPM, 0, a.reshape(-1)); vp.write(SPM, L * rows, b.reshape(-1))
+        vp.load_isram(512, words)
+        assert vp.run(512, src0=0, src1=L * rows, rslt=2 * L * rows) == 0
+        vp.sync()
+        res.append(vp.read(SPM, 2 * L * rows, L * n))
+    assert np.array_equal(res[0], res[1])
+    # and the answer is the negacyclic product: check one coefficient by direct convolution
+    q = mods[0]
+    j = 12345
+    acc = 0
+    for i in range(n):                             # X^n = -1: indices that wrap pick up a minus sign
+        if i <= j:
+            acc += int(a[0][i]) * int(b[0][j - i])
+        else:
+            acc -= int(a[0][i]) * int(b[0][j - i + n])
+    assert int(res[0][j]) == acc % q
