@@ -33,6 +33,16 @@ def _newest(paths) -> float:
     return max(os.path.getmtime(p) for p in paths)
 
 
+def build_ablation(level: int) -> str:
+    """Timing-experiment variant of the library (ALOHA_ABLATE=level); results are invalid."""
+    out = os.path.join(LIBDIR, f"libaloha_vp_ablate{level}.so")
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", f"-DALOHA_ABLATE={level}",
+           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     hdr_time = _newest([os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)])
@@ -58,3 +68,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    for a in sys.argv[1:]:
+        if a.startswith("--ablate="):
+            print(build_ablation(int(a.split("=")[1])))

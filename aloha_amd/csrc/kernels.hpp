@@ -15,6 +15,7 @@ struct ModCtx {
   u64 q;    // prime, 2^59 < q < 2^60
   u64 nq;   // 2^64 - q
   u64 mu;   // floor(2^121 / q)
+  u64 kc;   // floor(2^59 / (hi32(q) + 1)): quotient estimator of canon_any (modarith.hpp)
 };
 
 // element-wise ALU ops, one per decodable modalu opcode (src/vp/vxu/modalu.sv:22-37)
@@ -64,8 +65,8 @@ struct TileDesc {        // one row-pass tile of ntt_tile.hip
 
 // Row-pass tile lists for a batch (limbs that share a prime must be adjacent to be bundled):
 // tiles whose twiddle blocks fit LDS (bundles of >= 4 limbs) and the rest.
-void build_row_tiles(const LimbJob *h_jobs, uint32_t count, unsigned log_rows,
-                     std::vector<TileDesc> &lds_tiles, std::vector<TileDesc> &glb_tiles);
+void build_row_tiles(const LimbJob *h_jobs, uint32_t begin, uint32_t count, unsigned log_rows,
+                     std::vector<TileDesc> &uni_tiles, std::vector<TileDesc> &glb_tiles);
 
 // Radix-2 stage launches straight on global memory, any N: bring-up path, on-device
 // cross-check of the tile kernels and column passes of N < 2^16.
@@ -76,9 +77,11 @@ hipError_t ntt_radix2_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDe
                             unsigned logn, unsigned stage_begin, unsigned stage_end, bool inverse,
                             bool first_reads_src, bool last_scales, uint64_t *launches);
 
-// Batched tile transform: `count` limbs of 2^logn words, d_jobs as described at LimbJob.
-hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
-                          unsigned logn, bool inverse, const TileDesc *d_lds_tiles, uint32_t n_lds,
+// Tile transform of limbs [begin, begin+count) of a batch: d_jobs = the {src,dst} array,
+// d_inplace = the {dst,dst} array (same indexing); the tile lists cover exactly these limbs.
+hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *d_inplace,
+                          const PrimeDev *d_primes, uint32_t begin, uint32_t count, unsigned logn,
+                          bool inverse, const TileDesc *d_uni_tiles, uint32_t n_uni,
                           const TileDesc *d_glb_tiles, uint32_t n_glb, uint64_t *launches);
 
 }  // namespace k

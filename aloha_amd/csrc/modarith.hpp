@@ -173,8 +173,22 @@ ALOHA_DEV void ct_bfly_p32(u64 &X, u64 &Y, u64 w, u64 wp, u64 nq, u64 C) {
 // conditional subtraction by the borrow of the subtraction itself (exact 64-bit compare
 // for free): x >= m ? x - m : x
 ALOHA_DEV u64 csub_borrow(u64 x, u64 m) {
-  u64 d = x - m;
-  return x < m ? x : d;
+  u64 d;
+  const bool borrow = __builtin_usubll_overflow(x, m, &d);
+  return borrow ? x : d;
+}
+
+// Canonicalise ANY 64-bit x (used once per element at the end of a pass): estimate
+// k ~ floor(x / q) from the high words, subtract k*q, one conditional subtraction.
+//   qh = hi32(q) in [2^27, 2^28);  kc = floor(2^59 / (qh + 1)) < 2^32 (host-computed)
+//   k  = floor(hi32(x) * kc / 2^59) <= hi32(x) / (qh + 1) <= x / q      (never too large)
+//   x/q - k < (hi32(x)+1)/qh - hi32(x)/(qh+1) + 2^-27 + 1  < 2          (k >= floor(x/q) - 1)
+// so x - k*q lies in [0, 2q).  3 multiplier issues.
+ALOHA_DEV u64 canon_any(u64 x, u64 q, u64 nq, u32 kc) {
+  const u32 k = mulhi32_s(hi32(x), kc) >> 27;
+  u64 r = mad32_s(k, lo32(nq), x);                       // x + k*nq0 (carry into the high word)
+  r = pack64(lo32(r), hi32(r) + mullo32_s(k, hi32(nq)));  // + (k*nq1 << 32)   == x - k*q (mod 2^64)
+  return csub_borrow(r, q);
 }
 
 // ---- general product of two residues (Barrett, single-word ratio) -----------------------

@@ -42,26 +42,51 @@ namespace k {
 
 namespace {
 
-constexpr int LINES = 16;          // lines per tile
-constexpr int PTS = 256;           // points per line
-constexpr int PITCH = PTS + 1;     // LDS pitch in u64: odd => conflict-free 64-bit accesses
+constexpr int LINES = 16;          // lines per column tile
+constexpr int PITCH = 257;         // column-tile LDS pitch in u64: odd => conflict-free 64-bit accesses
 constexpr int TW_BLK = 256;        // twiddle entries per block
 
 struct alignas(16) tw_t { u64 w, wp; };
 
-// ---- butterflies ----------------------------------------------------------------------------
-// Harvey GS: X, Y < 2q  ->  X' = X + Y (- 2q) < 2q,  Y' = (X - Y + 2q) * w  < 2q.
-__device__ __forceinline__ void gs_bfly(u64 &X, u64 &Y, u64 w, u64 wp, u64 q, u64 twoq) {
-  const u64 s = csub_borrow(X + Y, twoq);
-  const u64 d = X + twoq - Y;
-  Y = mul_shoup_2q(d, w, wp, q);
-  X = s;
-}
+// Pointers that arrive through LimbJob / PrimeDev are generic; naming their address space lets
+// hipcc emit global_load/global_store (SGPR base + 32-bit lane offset + immediate) instead of
+// flat accesses with 64-bit per-lane address arithmetic, and scalar loads (s_load) for
+// wave-uniform twiddle reads.
+#define ALOHA_AS_GLOBAL __attribute__((address_space(1)))
+#define ALOHA_AS_CONST __attribute__((address_space(4)))
+typedef const ALOHA_AS_GLOBAL u64 *cgptr_t;
+typedef ALOHA_AS_GLOBAL u64 *gptr_t;
+typedef const ALOHA_AS_CONST tw_t *ctw_t;
 
-// radix-16 steps on 16 registers: sub-stage ss pairs v[i] with v[i + (8 >> ss)]; group g of
-// sub-stage ss takes twiddle tw(ss, g).
-template <typename TW>
-__device__ __forceinline__ void fwd_radix16(u64 (&v)[16], const TW &tw, u64 nq, u64 twoq) {
+// uniform (SGPR) value from a value the compiler cannot prove wave-uniform
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// ---- lazy ranges of the forward butterflies -----------------------------------------------------
+// Bounds are strict, in units of q: a register with bound b holds a value < b*q.  One relaxed
+// butterfly (approximate quotient, C = 4q) maps X < b*q, Y arbitrary to outputs < (b+4)*q,
+// which must stay <= 16q (< 2^64).  When b + 4 > 16 the X operands (only) of that sub-stage are
+// first reduced by one borrow-subtract of ceil(b/2)*q, leaving them < ceil(b/2)*q.
+constexpr int corr_t(int b) { return (b + 1) / 2; }
+constexpr bool need_corr(int b) { return b + 4 > 16; }
+constexpr int next_bound(int b) { return (need_corr(b) ? corr_t(b) : b) + 4; }
+constexpr int bound_after4(int b) { return next_bound(next_bound(next_bound(next_bound(b)))); }
+
+// radix-16 step on 16 registers: sub-stage ss pairs v[i] with v[i + (8 >> ss)]; group g of
+// sub-stage ss takes twiddle tw(ss, g).  BIN = input bound; output bound = bound_after4(BIN).
+// ALOHA_ABLATE (timing experiments only, results invalid): 1 = no butterflies (memory + LDS
+// skeleton), 2 = no global loads/stores (arithmetic + LDS skeleton).
+#ifndef ALOHA_ABLATE
+#define ALOHA_ABLATE 0
+#endif
+
+template <bool UNI, int BIN, typename TW>
+__device__ __forceinline__ void fwd_radix16(u64 (&v)[16], const TW &tw, u64 q, u64 nq) {
+#if ALOHA_ABLATE == 1
+  return;
+#endif
+  constexpr int B[5] = {BIN, next_bound(BIN), next_bound(next_bound(BIN)),
+                        next_bound(next_bound(next_bound(BIN))), bound_after4(BIN)};
+  const u64 fourq = q << 2;
 #pragma unroll
   for (int ss = 0; ss < 4; ss++) {
     const int half = 8 >> ss;
@@ -71,14 +96,26 @@ __device__ __forceinline__ void fwd_radix16(u64 (&v)[16], const TW &tw, u64 nq, 
 #pragma unroll
       for (int jj = 0; jj < half; jj++) {
         const int i0 = g * 2 * half + jj;
-        ct_bfly<false, true>(v[i0], v[i0 + half], t.w, t.wp, nq, twoq);
+        if (need_corr(B[ss])) v[i0] = csub_borrow(v[i0], q * (u64)corr_t(B[ss]));
+        ct_bfly<UNI, false>(v[i0], v[i0 + half], t.w, t.wp, nq, fourq);
       }
     }
   }
 }
 
-template <typename TW>
-__device__ __forceinline__ void inv_radix16(u64 (&v)[16], const TW &tw, u64 q, u64 twoq) {
+// Inverse (Gentleman-Sande) butterfly, every value < 4q:
+//   X' = X + Y (- 4q) < 4q,   Y' = (X - Y + 4q) * w  in [0, 4q)   (approximate-quotient Shoup)
+template <bool UNI>
+__device__ __forceinline__ void gs_bfly(u64 &X, u64 &Y, u64 w, u64 wp, u64 nq, u64 fourq) {
+  const u64 s = csub_borrow(X + Y, fourq);
+  const u64 d = X + fourq - Y;
+  Y = mul_shoup_4q<UNI>(d, w, wp, nq);
+  X = s;
+}
+
+template <bool UNI, typename TW>
+__device__ __forceinline__ void inv_radix16(u64 (&v)[16], const TW &tw, u64 q, u64 nq) {
+  const u64 fourq = q << 2;
 #pragma unroll
   for (int ss = 3; ss >= 0; ss--) {
     const int half = 8 >> ss;
@@ -88,145 +125,206 @@ __device__ __forceinline__ void inv_radix16(u64 (&v)[16], const TW &tw, u64 q, u
 #pragma unroll
       for (int jj = 0; jj < half; jj++) {
         const int i0 = g * 2 * half + jj;
-        gs_bfly(v[i0], v[i0 + half], t.w, t.wp, q, twoq);
+        gs_bfly<UNI>(v[i0], v[i0 + half], t.w, t.wp, nq, fourq);
       }
     }
   }
 }
 
-// twiddle accessors over one 256-entry block (LDS or global)
+// twiddle accessors over one 256-entry block
+__device__ __forceinline__ tw_t load_tw(ctw_t p) {
+  tw_t t;
+  t.w = p->w;
+  t.wp = p->wp;
+  return t;
+}
 struct TwStepA {                   // stages s' = 0..3: L = 2^ss + g   (same for every thread)
-  const tw_t *blk;
-  __device__ __forceinline__ tw_t operator()(int ss, int g) const { return blk[(1 << ss) + g]; }
+  ctw_t blk;
+  __device__ __forceinline__ tw_t operator()(int ss, int g) const { return load_tw(blk + (1 << ss) + g); }
 };
 struct TwStepB {                   // stages s' = 4..7: L = 2^(4+ss) + kh*2^ss + g
-  const tw_t *blk;
+  ctw_t blk;
   int kh;
   __device__ __forceinline__ tw_t operator()(int ss, int g) const {
-    return blk[(16 << ss) + (kh << ss) + g];
+    return load_tw(blk + (16 << ss) + (kh << ss) + g);
   }
 };
 
-// full canonicalisation of a value < 16q
-__device__ __forceinline__ u64 canon16(u64 x, u64 q) {
-  x = csub_borrow(x, q << 3);
-  x = csub_borrow(x, q << 2);
-  x = csub_borrow(x, q << 1);
-  return csub_borrow(x, q);
+// in-wave LDS hand-off: LDS instructions of one wave execute in issue order, so lanes of the
+// same wave need no s_barrier between a ds_write and a dependent ds_read -- only the compiler
+// must keep the order.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-}  // namespace
+// inverse last pass: multiply by N^-1 and canonicalise.  The reference halves at every stage
+// (halfred.sv:23-26); the product of the halvings is N^-1 and the canonical result is the same
+// (SURVEY A.2).
+__device__ __forceinline__ u64 scale_canon(u64 x, u64 ni, u64 nip, u64 q, u64 nq) {
+  const u64 r = mul_shoup_4q<true>(x, ni, nip, nq);          // < 4q
+  return csub_borrow(csub_borrow(r, q << 1), q);
+}
 
-namespace {
+// Intermediate formats between the passes of one transform:
+//   forward: column pass stores values < FWD_MID*q;   inverse: row pass stores values < 4q.
+// A FIRST pass reads memory operands: < 2^60 < 2q (q > 2^59), i.e. bound 2 -- the RTL's one
+// conditional subtract (modalu.sv:44-46) is subsumed by the lazy range.
+constexpr int FWD_IN = 2;
+constexpr int FWD_MID = bound_after4(bound_after4(FWD_IN));
+static_assert(bound_after4(bound_after4(FWD_MID)) <= 16 && FWD_MID <= 16, "forward lazy range overflows");
 
-// ---- the tile kernel ------------------------------------------------------------------------
-// ROWPASS false: column tile (blockIdx -> limb, column group); true: row tile (TileDesc).
-// INV selects GS.  TWLDS: twiddle blocks staged in LDS (needs rpt <= 4).
-// FIRST: inputs come from memory (< 2^60 < 2q) and get the RTL's one conditional subtract
-//        (modalu.sv:44-46); otherwise they are the previous pass's intermediate format.
-// LAST : outputs are canonical; otherwise intermediate format (forward < 8q, inverse < 2q).
-template <bool ROWPASS, bool INV, bool TWLDS, bool FIRST, bool LAST>
-__global__ __launch_bounds__(256) void ntt_tile_kernel(const LimbJob *__restrict__ jobs,
-                                                       const PrimeDev *__restrict__ primes,
-                                                       const TileDesc *__restrict__ tiles) {
+// ---- column pass (N = 2^16): 16 adjacent columns x 256 rows per workgroup ---------------------
+// A mapping: thread (col = tid & 15, pl = tid >> 4) holds rows pl + 16k   (stages 0..3)
+// B mapping: thread (col = tid & 15, kh = tid >> 4) holds rows 16*kh + j  (stages 4..7)
+// Both mappings touch memory in 128-byte row segments: forward loads in A and stores from B,
+// inverse loads in B and stores from A.  One LDS exchange and one barrier per tile.  The
+// stage 0..3 twiddles are the same for every thread (scalar loads -> SGPR operands).
+template <bool INV, bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict__ jobs,
+                                                      const PrimeDev *__restrict__ primes) {
   __shared__ u64 sdata[LINES * PITCH];
-  __shared__ tw_t stw[TWLDS ? 4 * TW_BLK : 1];
-
   const int tid = threadIdx.x;
-  const int fast = tid & 15, slow = tid >> 4;
-
-  // ---- tile geometry (wave-uniform) ----
-  uint32_t first_limb, pb_log, chunk;
-  if (ROWPASS) {
-    const TileDesc td = tiles[blockIdx.x];
-    first_limb = td.first_limb; pb_log = td.pb_log; chunk = td.chunk;
+  const uint32_t col = tid & 15, slow = tid >> 4;
+  const uint32_t limb = blockIdx.x >> 4, cg = blockIdx.x & 15;
+  const LimbJob jb = jobs[limb];
+  const PrimeDev *pr = &primes[jb.prime];
+  const u64 q = pr->m.q, nq = pr->m.nq;
+  ctw_t blk = (ctw_t)(INV ? pr->tw.inv_blk : pr->tw.fwd_blk);            // block 0
+  cgptr_t src = (cgptr_t)jb.src + cg * 16;                                // wave-uniform bases
+  gptr_t dst = (gptr_t)jb.dst + cg * 16;
+  const uint32_t offA = (slow << 8) + col, offB = (slow << 12) + col;     // 32-bit lane offsets
+  u64 v[16];
+  if (!INV) {
+    constexpr int BIN = FIRST ? FWD_IN : FWD_MID;
+#pragma unroll
+#if ALOHA_ABLATE == 2
+    for (int kk = 0; kk < 16; kk++) v[kk] = (u64)offA * (kk + 3) + q;
+#else
+    for (int kk = 0; kk < 16; kk++) v[kk] = (src + ((size_t)(16 * kk) << 8))[offA];
+#endif
+    fwd_radix16<true, BIN>(v, TwStepA{blk}, q, nq);
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) sdata[col * PITCH + slow + 16 * kk] = v[kk];
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++) v[jj] = sdata[col * PITCH + 16 * slow + jj];
+    fwd_radix16<false, bound_after4(BIN)>(v, TwStepB{blk, (int)slow}, q, nq);
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++) {
+#if ALOHA_ABLATE == 2
+      if (v[jj] != 0x123456789abcull) continue;
+#endif
+      (dst + ((size_t)jj << 8))[offB] = LAST ? canon_any(v[jj], q, nq, (u32)pr->m.kc) : v[jj];
+    }
   } else {
-    first_limb = blockIdx.x >> 4; pb_log = 4; chunk = blockIdx.x & 15;    // 16 groups of 16 columns
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++) v[jj] = (src + ((size_t)jj << 8))[offB];
+    inv_radix16<false>(v, TwStepB{blk, (int)slow}, q, nq);               // < 4q throughout
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++) sdata[col * PITCH + 16 * slow + jj] = v[jj];
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) v[kk] = sdata[col * PITCH + slow + 16 * kk];
+    inv_radix16<true>(v, TwStepA{blk}, q, nq);
+    const u64 ni = pr->tw.n_inv, nip = pr->tw.n_inv_shoup;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++)
+      (dst + ((size_t)(16 * kk) << 8))[offA] = LAST ? scale_canon(v[kk], ni, nip, q, nq) : v[kk];
   }
-  const uint32_t pb_mask = (1u << pb_log) - 1;
-  const uint32_t rpt = ROWPASS ? (16u >> pb_log) : 1u;                    // twiddle blocks in the tile
+}
+
+// ---- row pass: 16 lines of 256 contiguous points per workgroup, 4 lines per WAVE ------------------
+// The four waves of a workgroup are independent: each owns 4 lines and a private LDS region,
+// so the pass has no s_barrier at all (wave_lds_fence).  Lines of a tile are the same row of
+// 2^pb limbs that share a prime (TileDesc), so with pb >= 2 a wave's four lines use ONE twiddle
+// block: the first radix-16 step takes its 15 twiddles from SGPRs (scalar loads), the second
+// reads its kh-dependent ones through the vector cache (16 distinct 16-byte words per load).
+// A mapping: lane (pl = lane & 15, lw = lane >> 4) holds points pl + 16k  -- 128-byte segments
+// B mapping: lane (lw = lane & 3, kh = lane >> 2) holds points 16*kh + j
+// LDS slot of point p of wave-line lw: lw*RP + p + (p >> 4); RP = 280 (== 24 mod 32) makes the
+// B-mapping 64-bit reads conflict-free.
+constexpr int RP = 280;
+
+template <bool INV, bool UNIA, bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void ntt_row_kernel(const LimbJob *__restrict__ jobs,
+                                                      const PrimeDev *__restrict__ primes,
+                                                      const TileDesc *__restrict__ tiles) {
+  __shared__ u64 sdata[4][4 * RP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t w = uni((uint32_t)tid >> 6);
+  const TileDesc td = tiles[blockIdx.x];
+  const uint32_t first_limb = td.first_limb, pb_log = td.pb_log, chunk = td.chunk;
+  const uint32_t pb_mask = (1u << pb_log) - 1, rpt = 16u >> pb_log;
   const LimbJob j0 = jobs[first_limb];
   const PrimeDev *pr = &primes[j0.prime];
-  const u64 q = pr->m.q, nq = pr->m.nq, twoq = q << 1;
-  const tw_t *gtw = reinterpret_cast<const tw_t *>(INV ? pr->tw.inv_blk : pr->tw.fwd_blk) +
-                    (ROWPASS ? (size_t)(1 + chunk * rpt) * TW_BLK : 0);
+  const u64 q = pr->m.q, nq = pr->m.nq;
+  ctw_t gtw = (ctw_t)(INV ? pr->tw.inv_blk : pr->tw.fwd_blk) + TW_BLK;   // row blocks
+  u64 *lds = sdata[w];
 
-  if (TWLDS) {
-    for (uint32_t b = 0; b < rpt; b++) stw[b * TW_BLK + tid] = gtw[b * TW_BLK + tid];
-  }
-  const tw_t *twbase = TWLDS ? stw : gtw;
-
-  // ---- per-thread addressing ----
-  // step-A register mapping: thread (line, pl) holds points p = pl + 16k; the lane-fast index
-  // is the one that is contiguous in memory (points for rows, lines for columns).
-  const int lineA = ROWPASS ? slow : fast;
-  const int plA = ROWPASS ? fast : slow;
-  const u64 *srcA; u64 *dstA; uint32_t rselA;
-  if (ROWPASS) {
-    const LimbJob jb = jobs[first_limb + ((uint32_t)lineA & pb_mask)];
-    rselA = (uint32_t)lineA >> pb_log;
-    const size_t off = (size_t)(chunk * rpt + rselA) << 8;                // row * 256
-    srcA = jb.src + off; dstA = jb.dst + off;
-  } else {
-    rselA = 0;
-    srcA = j0.src + chunk * 16 + lineA; dstA = j0.dst + chunk * 16 + lineA;
-  }
-  constexpr int PSH = ROWPASS ? 0 : 8;                                    // point stride = 1 or 256 words
-  // step-B register mapping: thread (line = fast, kh = slow) holds points p = 16*kh + j
-  const int lineB = fast, khB = slow;
-  const uint32_t rselB = ROWPASS ? ((uint32_t)lineB >> pb_log) : 0;
+  const uint32_t plA = lane & 15, lwA = lane >> 4;
+  const uint32_t lwB = lane & 3, khB = lane >> 2;
+  const uint32_t lineA = 4 * w + lwA, lineB = 4 * w + lwB;
+  const uint32_t rowA = chunk * rpt + (lineA >> pb_log), rowB = chunk * rpt + (lineB >> pb_log);
+  const uint32_t rowU = chunk * rpt + ((4 * w) >> pb_log);               // wave-uniform when pb_log >= 2
+  ctw_t blkA = gtw + (size_t)(UNIA ? rowU : rowA) * TW_BLK;
+  ctw_t blkB = gtw + (size_t)(UNIA ? rowU : rowB) * TW_BLK;
+  const LimbJob jA = jobs[first_limb + (lineA & pb_mask)];
+  cgptr_t src = (cgptr_t)jA.src + ((size_t)rowA << 8) + plA;
+  gptr_t dst = (gptr_t)jA.dst + ((size_t)rowA << 8) + plA;
+  const uint32_t ldsA = lwA * RP + plA, ldsB = lwB * RP + 17 * khB;
 
   u64 v[16];
 #pragma unroll
-  for (int kk = 0; kk < 16; kk++) {
-    u64 x = srcA[(size_t)(plA + 16 * kk) << PSH];
-    if (FIRST) x = csub(x, q);
-    v[kk] = x;
-  }
-  if (TWLDS) __syncthreads();                                             // twiddle blocks visible
-
+#if ALOHA_ABLATE == 2
+  for (int kk = 0; kk < 16; kk++) v[kk] = (u64)ldsA * (kk + 3) + q;
+#else
+  for (int kk = 0; kk < 16; kk++) v[kk] = src[16 * kk];
+#endif
   if (!INV) {
-    // stages 0..3 in the A mapping, transpose, stages 4..7 in the B mapping
-    fwd_radix16(v, TwStepA{twbase + rselA * TW_BLK}, nq, twoq);           // < in + 8q  (< 16q)
+    constexpr int BIN = FIRST ? FWD_IN : FWD_MID;
+    fwd_radix16<UNIA, BIN>(v, TwStepA{blkA}, q, nq);
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) sdata[lineA * PITCH + plA + 16 * kk] = v[kk];
-    __syncthreads();
+    for (int kk = 0; kk < 16; kk++) lds[ldsA + 17 * kk] = v[kk];
+    wave_lds_fence();
 #pragma unroll
-    for (int jj = 0; jj < 16; jj++) v[jj] = csub_borrow(sdata[lineB * PITCH + 16 * khB + jj], q << 3);   // < 8q
-    fwd_radix16(v, TwStepB{twbase + rselB * TW_BLK, khB}, nq, twoq);      // < 16q
-#pragma unroll
-    for (int jj = 0; jj < 16; jj++) v[jj] = LAST ? canon16(v[jj], q) : csub_borrow(v[jj], q << 3);
-  } else {
-    // stages 7..4 need the B mapping first
-#pragma unroll
-    for (int kk = 0; kk < 16; kk++) sdata[lineA * PITCH + plA + 16 * kk] = v[kk];
-    __syncthreads();
-#pragma unroll
-    for (int jj = 0; jj < 16; jj++) v[jj] = sdata[lineB * PITCH + 16 * khB + jj];
-    inv_radix16(v, TwStepB{twbase + rselB * TW_BLK, khB}, q, twoq);       // < 2q throughout
-  }
-
-  // ---- back to the A mapping (second inverse step / coalesced stores) ----
-  // each thread rewrites exactly the LDS words it read in the B mapping: no barrier needed
-  // before the writes, one before the A-mapping reads.
-#pragma unroll
-  for (int jj = 0; jj < 16; jj++) sdata[lineB * PITCH + 16 * khB + jj] = v[jj];
-  __syncthreads();
-#pragma unroll
-  for (int kk = 0; kk < 16; kk++) v[kk] = sdata[lineA * PITCH + plA + 16 * kk];
-
-  if (INV) {
-    inv_radix16(v, TwStepA{twbase + rselA * TW_BLK}, q, twoq);
+    for (int jj = 0; jj < 16; jj++) v[jj] = lds[ldsB + jj];
+    fwd_radix16<false, bound_after4(BIN)>(v, TwStepB{blkB, (int)khB}, q, nq);
     if (LAST) {
-      // fused N^-1: the reference halves at every stage (halfred.sv:23-26); the product of
-      // the halvings is N^-1 and the canonical result is identical
+#pragma unroll
+      for (int jj = 0; jj < 16; jj++) v[jj] = canon_any(v[jj], q, nq, (u32)pr->m.kc);
+    }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) lds[ldsA + 17 * kk] = v[kk];
+    wave_lds_fence();
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++) v[jj] = lds[ldsB + jj];
+    inv_radix16<false>(v, TwStepB{blkB, (int)khB}, q, nq);               // < 4q throughout
+  }
+  // back to the A mapping: second inverse step / 128-byte-segment stores
+  wave_lds_fence();
+#pragma unroll
+  for (int jj = 0; jj < 16; jj++) lds[ldsB + jj] = v[jj];
+  wave_lds_fence();
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++) v[kk] = lds[ldsA + 17 * kk];
+  if (INV) {
+    inv_radix16<UNIA>(v, TwStepA{blkA}, q, nq);
+    if (LAST) {
       const u64 ni = pr->tw.n_inv, nip = pr->tw.n_inv_shoup;
 #pragma unroll
-      for (int kk = 0; kk < 16; kk++) v[kk] = csub(mul_shoup_2q(v[kk], ni, nip, q), q);
+      for (int kk = 0; kk < 16; kk++) v[kk] = scale_canon(v[kk], ni, nip, q, nq);
     }
   }
 #pragma unroll
-  for (int kk = 0; kk < 16; kk++) dstA[(size_t)(plA + 16 * kk) << PSH] = v[kk];
+  for (int kk = 0; kk < 16; kk++) {
+#if ALOHA_ABLATE == 2
+    if (v[kk] != 0x123456789abcull) continue;
+#endif
+    dst[16 * kk] = v[kk];
+  }
 }
 
 // ---- radix-2 stage kernels (any N; column passes of N < 2^16; bring-up cross-check) ---------
@@ -249,7 +347,7 @@ __global__ __launch_bounds__(256) void ntt_radix2_fwd_stage(const LimbJob *__res
   jb.dst[j + t] = submod(U, V, q);
 }
 
-// Inverse stage with t = 2^u (h = N/2t groups): inputs < 2q, canonical out, no halving; the
+// Inverse stage with t = 2^u (h = N/2t groups): inputs < 4q, canonical out, no halving; the
 // final stage (scale = 1) multiplies both outputs by N^-1.
 __global__ __launch_bounds__(256) void ntt_radix2_inv_stage(const LimbJob *__restrict__ jobs,
                                                             const PrimeDev *__restrict__ primes,
@@ -262,7 +360,8 @@ __global__ __launch_bounds__(256) void ntt_radix2_inv_stage(const LimbJob *__res
   const uint32_t i = b / t, jj = b % t, j = 2 * i * t + jj;
   const tw_t tw = reinterpret_cast<const tw_t *>(pr->tw.inv)[h + i];
   const u64 *src = first ? jb.src : jb.dst;
-  u64 U = csub(src[j], q), V = csub(src[j + t], q);
+  // the first stage may read the row pass's intermediate format (< 4q); later stages read canonical data
+  u64 U = csub(csub(src[j], q << 1), q), V = csub(csub(src[j + t], q << 1), q);
   u64 s0 = addmod(U, V, q);
   u64 s1 = csub(mul_shoup_2q(submod(U, V, q), tw.w, tw.wp, q), q);
   if (scale) {
@@ -276,24 +375,24 @@ __global__ __launch_bounds__(256) void ntt_radix2_inv_stage(const LimbJob *__res
 }  // namespace
 
 // ---- host side --------------------------------------------------------------------------------
-void build_row_tiles(const LimbJob *h_jobs, uint32_t count, unsigned log_rows,
-                     std::vector<TileDesc> &lds_tiles, std::vector<TileDesc> &glb_tiles) {
-  const uint32_t rows = 1u << log_rows;
-  uint32_t i = 0;
-  while (i < count) {
+void build_row_tiles(const LimbJob *h_jobs, uint32_t begin, uint32_t count, unsigned log_rows,
+                     std::vector<TileDesc> &uni_tiles, std::vector<TileDesc> &glb_tiles) {
+  const uint32_t rows = 1u << log_rows, end = begin + count;
+  uint32_t i = begin;
+  while (i < end) {
     uint32_t run = 1;
-    while (i + run < count && h_jobs[i + run].prime == h_jobs[i].prime) run++;
+    while (i + run < end && h_jobs[i + run].prime == h_jobs[i].prime) run++;
     uint32_t done = 0;
     while (done < run) {
       uint32_t pb_log = 4;
       while ((1u << pb_log) > run - done) pb_log--;
-      uint32_t rpt = 16u >> pb_log;
-      if (rpt > rows) {                     // tiny transforms: fewer rows than a tile holds
-        // not expressible as a full tile; signalled to the caller by an empty list
-        lds_tiles.clear(); glb_tiles.clear();
+      const uint32_t rpt = 16u >> pb_log;
+      if (rpt > rows) {                     // fewer rows than a tile holds: no tile form
+        uni_tiles.clear(); glb_tiles.clear();
         return;
       }
-      std::vector<TileDesc> &dst = (rpt <= 4) ? lds_tiles : glb_tiles;
+      // bundles of >= 4 limbs give every wave (4 lines) a single twiddle block
+      std::vector<TileDesc> &dst = (pb_log >= 2) ? uni_tiles : glb_tiles;
       for (uint32_t c = 0; c < rows / rpt; c++) dst.push_back(TileDesc{i + done, (uint16_t)pb_log, (uint16_t)c});
       done += 1u << pb_log;
     }
@@ -301,16 +400,24 @@ void build_row_tiles(const LimbJob *h_jobs, uint32_t count, unsigned log_rows,
   }
 }
 
-template <bool ROWPASS, bool INV, bool FIRST, bool LAST>
-static void launch_tiles(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes,
-                         const TileDesc *d_tiles, uint32_t ntiles, bool twlds, uint64_t *launches) {
+template <bool INV, bool FIRST, bool LAST>
+static void launch_cols(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
+                        uint64_t *launches) {
+  if (!count) return;
+  hipLaunchKernelGGL((ntt_col_kernel<INV, FIRST, LAST>), dim3(count * 16), dim3(256), 0, st, d_jobs, d_primes);
+  if (launches) ++*launches;
+}
+
+template <bool INV, bool FIRST, bool LAST>
+static void launch_rows(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes,
+                        const TileDesc *d_tiles, uint32_t ntiles, bool uniform, uint64_t *launches) {
   if (!ntiles) return;
-  if (twlds)
-    hipLaunchKernelGGL((ntt_tile_kernel<ROWPASS, INV, true, FIRST, LAST>), dim3(ntiles), dim3(256), 0, st,
-                       d_jobs, d_primes, d_tiles);
+  if (uniform)
+    hipLaunchKernelGGL((ntt_row_kernel<INV, true, FIRST, LAST>), dim3(ntiles), dim3(256), 0, st, d_jobs,
+                       d_primes, d_tiles);
   else
-    hipLaunchKernelGGL((ntt_tile_kernel<ROWPASS, INV, false, FIRST, LAST>), dim3(ntiles), dim3(256), 0, st,
-                       d_jobs, d_primes, d_tiles);
+    hipLaunchKernelGGL((ntt_row_kernel<INV, false, FIRST, LAST>), dim3(ntiles), dim3(256), 0, st, d_jobs,
+                       d_primes, d_tiles);
   if (launches) ++*launches;
 }
 
@@ -332,33 +439,31 @@ hipError_t ntt_radix2_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDe
   return hipGetLastError();
 }
 
-hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
-                          unsigned logn, bool inverse, const TileDesc *d_lds_tiles, uint32_t n_lds,
-                          const TileDesc *d_glb_tiles, uint32_t n_glb, uint64_t *launches) {
+hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *inplace, const PrimeDev *d_primes,
+                          uint32_t begin, uint32_t count, unsigned logn, bool inverse, const TileDesc *d_lds_tiles,
+                          uint32_t n_lds, const TileDesc *d_glb_tiles, uint32_t n_glb, uint64_t *launches) {
   if (logn < 10 || logn > 16) return hipErrorInvalidValue;
   const unsigned n1 = logn - 8;
   const bool col_tiles = (n1 == 8);
   if (!inverse) {
     if (col_tiles) {
-      launch_tiles<false, false, true, false>(st, d_jobs, d_primes, nullptr, count * 16, true, launches);
-      launch_tiles<true, false, false, true>(st, d_jobs, d_primes, d_lds_tiles, n_lds, true, launches);
-      launch_tiles<true, false, false, true>(st, d_jobs, d_primes, d_glb_tiles, n_glb, false, launches);
+      launch_cols<false, true, false>(st, d_jobs + begin, d_primes, count, launches);
+      launch_rows<false, false, true>(st, inplace, d_primes, d_lds_tiles, n_lds, true, launches);
+      launch_rows<false, false, true>(st, inplace, d_primes, d_glb_tiles, n_glb, false, launches);
     } else {
-      hipError_t e = ntt_radix2_batch(st, d_jobs, d_primes, count, logn, 0, n1, false, true, false, launches);
+      hipError_t e = ntt_radix2_batch(st, d_jobs + begin, d_primes, count, logn, 0, n1, false, true, false, launches);
       if (e != hipSuccess) return e;
-      // radix-2 stages wrote canonical data to dst; the row tiles then run in place on dst
-      launch_tiles<true, false, true, true>(st, d_jobs + count, d_primes, d_lds_tiles, n_lds, true, launches);
-      launch_tiles<true, false, true, true>(st, d_jobs + count, d_primes, d_glb_tiles, n_glb, false, launches);
+      // the radix-2 stages left canonical data in dst; the row tiles run in place on dst
+      launch_rows<false, true, true>(st, inplace, d_primes, d_lds_tiles, n_lds, true, launches);
+      launch_rows<false, true, true>(st, inplace, d_primes, d_glb_tiles, n_glb, false, launches);
     }
   } else {
+    launch_rows<true, true, false>(st, d_jobs, d_primes, d_lds_tiles, n_lds, true, launches);
+    launch_rows<true, true, false>(st, d_jobs, d_primes, d_glb_tiles, n_glb, false, launches);
     if (col_tiles) {
-      launch_tiles<true, true, true, false>(st, d_jobs, d_primes, d_lds_tiles, n_lds, true, launches);
-      launch_tiles<true, true, true, false>(st, d_jobs, d_primes, d_glb_tiles, n_glb, false, launches);
-      launch_tiles<false, true, false, true>(st, d_jobs + count, d_primes, nullptr, count * 16, true, launches);
+      launch_cols<true, false, true>(st, inplace + begin, d_primes, count, launches);
     } else {
-      launch_tiles<true, true, true, false>(st, d_jobs, d_primes, d_lds_tiles, n_lds, true, launches);
-      launch_tiles<true, true, true, false>(st, d_jobs, d_primes, d_glb_tiles, n_glb, false, launches);
-      hipError_t e = ntt_radix2_batch(st, d_jobs + count, d_primes, count, logn, 8, logn, true, true, true, launches);
+      hipError_t e = ntt_radix2_batch(st, inplace + begin, d_primes, count, logn, 8, logn, true, true, true, launches);
       if (e != hipSuccess) return e;
     }
   }

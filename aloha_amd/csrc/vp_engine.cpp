@@ -16,7 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -44,11 +46,29 @@ struct PrimeSlot {
   u64 *d_tables = nullptr;       // one allocation: fwd | inv | fwd_blk | inv_blk
 };
 
-struct BatchPlan {               // cached device-side description of the last batched transform
-  std::vector<LimbJob> jobs;     // 2*count entries
+constexpr size_t kMaxPlans = 128;
+
+struct PlanChunk {               // limbs [limb_begin, +limb_count) and their row-pass tiles
+  uint32_t limb_begin = 0, limb_count = 0;
+  uint32_t uni_off = 0, n_uni = 0, glb_off = 0, n_glb = 0;
+};
+
+struct TransformPlan {           // device-side description of one batched transform, cached
+  std::vector<LimbJob> jobs;     // 2*count entries: {src,dst} then the in-place form {dst,dst}
   unsigned logn = 0;
-  uint32_t n_lds = 0, n_glb = 0;
-  bool valid = false;
+  std::vector<PlanChunk> chunks; // empty => radix-2 stage launches only
+  LimbJob *d_jobs = nullptr;
+  TileDesc *d_tiles = nullptr;
+  ~TransformPlan() {
+    if (d_jobs) (void)hipFree(d_jobs);
+    if (d_tiles) (void)hipFree(d_tiles);
+  }
+};
+
+struct RowsKey {                 // arguments of aloha_vp_ntt_rows, for the argument-level cache
+  int space = 0; uint64_t dst_row = 0, src_row = 0; uint32_t log_n = 0, count = 0;
+  std::vector<uint64_t> moduli;
+  std::vector<LimbJob> jobs;
 };
 
 }  // namespace
@@ -69,11 +89,10 @@ struct aloha_vp {
   std::vector<PrimeSlot> slots;
   std::map<std::pair<uint64_t, unsigned>, uint32_t> slot_of;
   PrimeDev *d_primes = nullptr;
-  // batched-transform staging
-  LimbJob *d_jobs = nullptr;
-  TileDesc *d_tiles = nullptr;
-  size_t jobs_cap = 0, tiles_cap = 0;
-  BatchPlan plan;
+  // batched transforms
+  std::vector<std::unique_ptr<TransformPlan>> plans;
+  std::vector<RowsKey> rows_cache;
+  uint32_t chunk_limbs = 128;    // limbs per chunk of a batched transform (0 = whole batch)
   aloha_vp_stats stats{};
   std::string err;
 };
@@ -115,7 +134,7 @@ aloha_status vl_logn(uint64_t vl_bits, unsigned max_logn, unsigned *logn) {
 
 bool modulus_ok(uint64_t q) { return q > (1ull << 59) && q < (1ull << 60) && aloha::nt::is_prime(q); }
 
-ModCtx modctx(uint64_t q) { return ModCtx{q, 0 - q, aloha::nt::barrett_mu(q)}; }
+ModCtx modctx(uint64_t q) { return ModCtx{q, 0 - q, aloha::nt::barrett_mu(q), (1ull << 59) / ((q >> 32) + 1)}; }
 
 // Twiddle set for (q, N): generated on first use, kept for the life of the handle.
 aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
@@ -174,44 +193,61 @@ aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
 aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, unsigned logn, bool inverse) {
   const uint32_t count = (uint32_t)jobs1.size();
   if (!count) return ALOHA_OK;
-  // reuse the uploaded plan when the job list repeats (steady-state batches)
-  bool same = vp->plan.valid && vp->plan.logn == logn && vp->plan.jobs.size() == 2 * (size_t)count &&
-              memcmp(vp->plan.jobs.data(), jobs1.data(), count * sizeof(LimbJob)) == 0;
-  if (!same) {
-    std::vector<LimbJob> jobs(jobs1);
-    jobs.resize(2 * (size_t)count);
-    for (uint32_t i = 0; i < count; i++) { jobs[count + i] = jobs1[i]; jobs[count + i].src = jobs1[i].dst; }
-    std::vector<TileDesc> lds, glb;
-    if (!(vp->flags & ALOHA_FLAG_RADIX2_ONLY)) aloha::k::build_row_tiles(jobs.data(), count, logn - 8, lds, glb);
-    if (jobs.size() > vp->jobs_cap) {
-      if (vp->d_jobs) HIPCK(vp, hipFree(vp->d_jobs));
-      vp->jobs_cap = jobs.size() * 2;
-      HIPCK(vp, hipMalloc(&vp->d_jobs, vp->jobs_cap * sizeof(LimbJob)));
+  // Plans (device job/tile arrays + chunk schedule) are cached: a steady-state caller that
+  // repeats a batch pays only for the kernel launches.
+  TransformPlan *plan = nullptr;
+  for (auto &p : vp->plans)
+    if (p->logn == logn && p->jobs.size() == 2 * (size_t)count &&
+        memcmp(p->jobs.data(), jobs1.data(), count * sizeof(LimbJob)) == 0) { plan = p.get(); break; }
+  if (!plan) {
+    std::unique_ptr<TransformPlan> np(new TransformPlan());
+    np->logn = logn;
+    np->jobs = jobs1;
+    np->jobs.resize(2 * (size_t)count);
+    for (uint32_t i = 0; i < count; i++) { np->jobs[count + i] = jobs1[i]; np->jobs[count + i].src = jobs1[i].dst; }
+    // Chunk schedule: both passes of a chunk run back to back so that the intermediate
+    // (column-pass output) is still in the 256 MiB Infinity Cache when the row pass reads it.
+    const uint32_t ch = vp->chunk_limbs ? vp->chunk_limbs : count;
+    std::vector<TileDesc> tiles;
+    bool tiled = !(vp->flags & ALOHA_FLAG_RADIX2_ONLY);
+    for (uint32_t b = 0; b < count && tiled; b += ch) {
+      const uint32_t n = std::min(ch, count - b);
+      std::vector<TileDesc> uni, glb;
+      aloha::k::build_row_tiles(np->jobs.data(), b, n, logn - 8, uni, glb);
+      if (uni.empty() && glb.empty()) { tiled = false; break; }
+      PlanChunk pc;
+      pc.limb_begin = b; pc.limb_count = n;
+      pc.uni_off = (uint32_t)tiles.size(); pc.n_uni = (uint32_t)uni.size();
+      tiles.insert(tiles.end(), uni.begin(), uni.end());
+      pc.glb_off = (uint32_t)tiles.size(); pc.n_glb = (uint32_t)glb.size();
+      tiles.insert(tiles.end(), glb.begin(), glb.end());
+      np->chunks.push_back(pc);
     }
-    const size_t ntiles = lds.size() + glb.size();
-    if (ntiles > vp->tiles_cap) {
-      if (vp->d_tiles) HIPCK(vp, hipFree(vp->d_tiles));
-      vp->tiles_cap = ntiles * 2;
-      HIPCK(vp, hipMalloc(&vp->d_tiles, vp->tiles_cap * sizeof(TileDesc)));
+    if (!tiled) np->chunks.clear();
+    HIPCK(vp, hipMalloc(&np->d_jobs, np->jobs.size() * sizeof(LimbJob)));
+    HIPCK(vp, hipMemcpyAsync(np->d_jobs, np->jobs.data(), np->jobs.size() * sizeof(LimbJob), hipMemcpyHostToDevice, vp->stream));
+    if (!tiles.empty()) {
+      HIPCK(vp, hipMalloc(&np->d_tiles, tiles.size() * sizeof(TileDesc)));
+      HIPCK(vp, hipMemcpyAsync(np->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, vp->stream));
     }
-    // the previous plan may still be read by kernels in flight on the stream: stream-ordered copies
-    HIPCK(vp, hipMemcpyAsync(vp->d_jobs, jobs.data(), jobs.size() * sizeof(LimbJob), hipMemcpyHostToDevice, vp->stream));
-    if (!lds.empty()) HIPCK(vp, hipMemcpyAsync(vp->d_tiles, lds.data(), lds.size() * sizeof(TileDesc), hipMemcpyHostToDevice, vp->stream));
-    if (!glb.empty()) HIPCK(vp, hipMemcpyAsync(vp->d_tiles + lds.size(), glb.data(), glb.size() * sizeof(TileDesc), hipMemcpyHostToDevice, vp->stream));
     HIPCK(vp, hipStreamSynchronize(vp->stream));    // pageable sources go out of scope
-    vp->plan.jobs.swap(jobs);
-    vp->plan.logn = logn;
-    vp->plan.n_lds = (uint32_t)lds.size();
-    vp->plan.n_glb = (uint32_t)glb.size();
-    vp->plan.valid = true;
+    if (vp->plans.size() >= kMaxPlans) {            // evict the oldest; its kernels have drained (sync above)
+      vp->plans.erase(vp->plans.begin());
+    }
+    plan = np.get();
+    vp->plans.push_back(std::move(np));
   }
   uint64_t launches = 0;
-  hipError_t e;
-  if (vp->plan.n_lds + vp->plan.n_glb == 0) {
-    e = aloha::k::ntt_radix2_batch(vp->stream, vp->d_jobs, vp->d_primes, count, logn, 0, logn, inverse, true, true, &launches);
+  hipError_t e = hipSuccess;
+  if (plan->chunks.empty()) {
+    e = aloha::k::ntt_radix2_batch(vp->stream, plan->d_jobs, vp->d_primes, count, logn, 0, logn, inverse, true, true, &launches);
   } else {
-    e = aloha::k::ntt_tile_batch(vp->stream, vp->d_jobs, vp->d_primes, count, logn, inverse, vp->d_tiles,
-                                 vp->plan.n_lds, vp->d_tiles + vp->plan.n_lds, vp->plan.n_glb, &launches);
+    for (const PlanChunk &pc : plan->chunks) {
+      e = aloha::k::ntt_tile_batch(vp->stream, plan->d_jobs, plan->d_jobs + count, vp->d_primes, pc.limb_begin,
+                                   pc.limb_count, logn, inverse, plan->d_tiles + pc.uni_off, pc.n_uni,
+                                   plan->d_tiles + pc.glb_off, pc.n_glb, &launches);
+      if (e != hipSuccess) break;
+    }
   }
   vp->stats.kernel_launches += launches;
   if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "transform launch failed: %s", hipGetErrorString(e));
@@ -276,6 +312,7 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   vp->spm_rows = cfg->spm_rows;
   vp->ksk_rows = cfg->ksk_rows;
   vp->max_logn = cfg->max_log_n;
+  if (const char *e = getenv("ALOHA_NTT_CHUNK")) vp->chunk_limbs = (uint32_t)strtoul(e, nullptr, 10);
   vp->inst.assign(ALOHA_IRAM_DEPTH, 0);
   vp->imm.assign(ALOHA_IRAM_DEPTH, 0);
   auto bail = [&](const char *what) {
@@ -313,8 +350,7 @@ void aloha_vp_destroy(aloha_vp *vp) {
   if (vp->d_vreg) (void)hipFree(vp->d_vreg);
   if (vp->d_scratch) (void)hipFree(vp->d_scratch);
   if (vp->d_primes) (void)hipFree(vp->d_primes);
-  if (vp->d_jobs) (void)hipFree(vp->d_jobs);
-  if (vp->d_tiles) (void)hipFree(vp->d_tiles);
+  vp->plans.clear();
   if (vp->own_stream && vp->stream) (void)hipStreamDestroy(vp->stream);
   delete vp;
 }
@@ -513,6 +549,11 @@ aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64
   const uint64_t bytes = (uint64_t)count * rows_per_limb * ALOHA_ROW_BYTES;
   u64 *src = space_ptr(vp, space, src_row, bytes), *dst = space_ptr(vp, space, dst_row, bytes);
   if (!src || !dst) return fail(vp, ALOHA_ERR_ADDR, "ntt_rows: %u limbs at rows %llu/%llu outside space %d", count, (u64)src_row, (u64)dst_row, space);
+  // steady state: identical arguments => reuse the resolved job list (no prime checks, no allocation)
+  for (const RowsKey &k : vp->rows_cache)
+    if (k.space == space && k.dst_row == dst_row && k.src_row == src_row && k.log_n == log_n && k.count == count &&
+        memcmp(k.moduli.data(), moduli, (size_t)count * 8) == 0)
+      return run_transforms(vp, k.jobs, log_n, inverse != 0);
   std::vector<LimbJob> jobs(count);
   uint64_t last_q = 0;
   uint32_t last_slot = 0;
@@ -525,6 +566,12 @@ aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64
     }
     jobs[i] = LimbJob{src + ((size_t)i << log_n), dst + ((size_t)i << log_n), last_slot, 0};
   }
+  if (vp->rows_cache.size() >= kMaxPlans) vp->rows_cache.erase(vp->rows_cache.begin());
+  RowsKey key;
+  key.space = space; key.dst_row = dst_row; key.src_row = src_row; key.log_n = log_n; key.count = count;
+  key.moduli.assign(moduli, moduli + count);
+  key.jobs = jobs;
+  vp->rows_cache.push_back(std::move(key));
   return run_transforms(vp, jobs, log_n, inverse != 0);
 }
 

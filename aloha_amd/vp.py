@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaloha_vp.so")
+LIB_PATH = os.environ.get("ALOHA_VP_LIB") or os.path.join(_HERE, "lib", "libaloha_vp.so")
 
 SPM, KSK = 0, 1
 ROW_BYTES = 1024
