@@ -92,7 +92,7 @@ struct aloha_vp {
   // batched transforms
   std::vector<std::unique_ptr<TransformPlan>> plans;
   std::vector<RowsKey> rows_cache;
-  uint32_t chunk_limbs = 128;    // limbs per chunk of a batched transform (0 = whole batch)
+  uint32_t chunk_limbs = 0;      // limbs per chunk of a batched transform (0 = whole batch; chunking did not pay)
   aloha_vp_stats stats{};
   std::string err;
 };
