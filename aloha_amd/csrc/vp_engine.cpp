@@ -428,118 +428,276 @@ aloha_status aloha_vp_sync(aloha_vp *vp) {
   return ALOHA_OK;
 }
 
-aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row, uint64_t rslt_row,
-                          uint64_t ksk_row, uint64_t step) {
+}  // extern "C" (reopened after the sequencer)
+
+// ---- the sequencer ---------------------------------------------------------------------------
+// Plain sequential semantics (one instruction in flight, seq_top.v:343-413) with three exact
+// program-level fusions, all disabled by ALOHA_FLAG_NO_FUSION:
+//   * vle is zero-copy: the register ALIASES the memory rows until either is overwritten;
+//   * `op vd, ...; vse vd, Z` with vd dead afterwards writes straight to Z;
+//   * runs of `vle vA, X; vntt|vintt vB, vA; vse vB, Y` (any vsetq in between, vA/vB dead
+//     afterwards) are collected into ONE batched tile transform over all their limbs.
+// Vector registers are not observable after `break`, memory is: every byte a vse
+// writes is identical to the unfused execution, in program order.
+namespace {
+
+struct Decoded {
+  unsigned funct6, vs2, vs1, funct3, vd;
+  uint64_t imm;
+};
+
+inline Decoded decode_at(const aloha_vp *vp, uint32_t pc) {                // expander.v:123-130
+  const uint32_t inst = vp->inst[pc];
+  return Decoded{inst >> 26, (inst >> 20) & 31, (inst >> 15) & 31, (inst >> 12) & 7, (inst >> 7) & 31, vp->imm[pc]};
+}
+
+bool reads_reg(const Decoded &d, unsigned r) {
+  switch (d.funct6) {
+    case 0x01: case 0x05: case 0x09:
+      if (d.funct3 == 0) return d.vs1 == r || d.vs2 == r;
+      if (d.funct3 == 1) return d.vs1 == r;
+      if (d.funct3 == 2) return d.vs2 == r;
+      return false;
+    case 0x0d: case 0x11: case 0x15: case 0x19: case 0x02: case 0x06: case 0x07: return d.vs1 == r;
+    default: return false;
+  }
+}
+
+bool writes_reg(const Decoded &d, unsigned r) {
+  switch (d.funct6) {
+    case 0x01: case 0x05: case 0x09: case 0x0d: case 0x11: case 0x15: case 0x19: case 0x02: case 0x06: case 0x03:
+      return d.vd == r;
+    default: return false;
+  }
+}
+
+// is register r dead from pc on (overwritten or program end before any read)?
+bool dead_from(const aloha_vp *vp, uint32_t pc, unsigned r) {
+  for (; pc < ALOHA_IRAM_DEPTH; pc++) {
+    const Decoded d = decode_at(vp, pc);
+    if (d.funct6 == 0x10) return true;
+    if (reads_reg(d, r)) return false;
+    if (writes_reg(d, r)) return true;
+  }
+  return true;
+}
+
+inline bool overlap(const u64 *a, const u64 *b, size_t n) { return a < b + n && b < a + n; }
+
+}  // namespace
+
+extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
+                                     uint64_t rslt_row, uint64_t ksk_row, uint64_t step) {
   if (!vp) return ALOHA_ERR_ARG;
   const uint64_t csr[4] = {src0_row, src1_row, rslt_row, ksk_row};
   hipStream_t st = vp->stream;
+  const bool fuse = !(vp->flags & ALOHA_FLAG_NO_FUSION);
+  const u64 *alias[ALOHA_NVREG] = {nullptr};                // non-null: the register's value is memory at this address
+  std::vector<LimbJob> batch;                               // pending fused transforms
+  bool batch_inv = false;
+  unsigned batch_logn = 0;
+
+  auto rd = [&](unsigned r) -> const u64 * { return alias[r] ? alias[r] : vreg(vp, r); };
+  auto flush = [&]() -> aloha_status {
+    if (batch.empty()) return ALOHA_OK;
+    aloha_status s = run_transforms(vp, batch, batch_logn, batch_inv);
+    batch.clear();
+    return s;
+  };
+  // Memory [dst, dst+n) is about to be written at next_pc-1: registers aliasing it either die
+  // (dropped) or get their value copied out first.
+  auto before_mem_write = [&](const u64 *dst, size_t n, uint32_t next_pc) -> aloha_status {
+    for (unsigned r = 0; r < ALOHA_NVREG; r++) {
+      if (!alias[r] || !overlap(alias[r], dst, n)) continue;
+      if (!dead_from(vp, next_pc, r)) {
+        aloha_status s = flush();                            // the copy must see memory as of program order
+        if (s) return s;
+        HIPCK(vp, hipMemcpyAsync(vreg(vp, r), alias[r], n * 8, hipMemcpyDeviceToDevice, st));
+      }
+      alias[r] = nullptr;
+    }
+    return ALOHA_OK;
+  };
+#define ALOHA_RUN_FAIL(status, ...) do { (void)flush(); return fail(vp, status, __VA_ARGS__); } while (0)
+#define ALOHA_RUN_CK(expr) do { aloha_status s_ = (expr); if (s_) { (void)flush(); return s_; } } while (0)
+
   for (;; pc++) {
-    if (pc >= ALOHA_IRAM_DEPTH) return fail(vp, ALOHA_ERR_NOBREAK, "no break before the end of the ROM");
-    // field split: expander.v:123-130
-    const uint32_t inst = vp->inst[pc];
-    const uint64_t imm = vp->imm[pc];
-    const unsigned funct6 = inst >> 26, vs2 = (inst >> 20) & 31, vs1 = (inst >> 15) & 31;
-    const unsigned funct3 = (inst >> 12) & 7, vd = (inst >> 7) & 31;
+    if (pc >= ALOHA_IRAM_DEPTH) ALOHA_RUN_FAIL(ALOHA_ERR_NOBREAK, "no break before the end of the ROM");
+    const Decoded d = decode_at(vp, pc);
+    const unsigned funct6 = d.funct6, vs2 = d.vs2, vs1 = d.vs1, funct3 = d.funct3, vd = d.vd;
+    const uint64_t imm = d.imm;
     vp->stats.instructions++;
-    const bool is_vec = !(funct6 == 0x04 || funct6 == 0x08 || funct6 == 0x0c || funct6 == 0x10 || funct6 == 0x00);
+    const bool is_cfg = funct6 == 0x04 || funct6 == 0x08 || funct6 == 0x0c || funct6 == 0x10 || funct6 == 0x00;
     unsigned logn = 0;
     uint32_t n = 0;
     const uint64_t q = vp->q;
-    if (is_vec) {
+    if (!is_cfg) {
       aloha_status s = vl_logn(vp->vl_bits, vp->max_logn, &logn);
-      if (s) return fail(vp, s, "pc %u: VL = %llu bits", pc, (u64)vp->vl_bits);
+      if (s) ALOHA_RUN_FAIL(s, "pc %u: VL = %llu bits", pc, (u64)vp->vl_bits);
       n = 1u << logn;
       if (funct6 != 0x03 && funct6 != 0x07 && funct6 != 0x19 && !(q > (1ull << 59) && q < (1ull << 60)))
-        return fail(vp, ALOHA_ERR_MODULUS, "pc %u: arithmetic with q = %#llx", pc, (u64)q);
+        ALOHA_RUN_FAIL(ALOHA_ERR_MODULUS, "pc %u: arithmetic with q = %#llx", pc, (u64)q);
     }
+    // a following `vse vd, Z` this instruction may write to directly
+    auto direct_store = [&](u64 **out) -> aloha_status {
+      *out = nullptr;
+      if (!fuse || pc + 1 >= ALOHA_IRAM_DEPTH) return ALOHA_OK;
+      const Decoded nx = decode_at(vp, pc + 1);
+      if (nx.funct6 != 0x07 || nx.vs1 != vd || !dead_from(vp, pc + 2, vd)) return ALOHA_OK;
+      u64 *z = mem_rows(vp, nx.imm, false, csr, n / kLanes);
+      if (!z) return ALOHA_OK;                               // let the vse itself report the address error
+      *out = z;
+      return ALOHA_OK;
+    };
+
     switch (funct6) {
-      case 0x10: return ALOHA_OK;                                  // break   expander.v:141-151
+      case 0x10: return flush();                                   // break   expander.v:141-151
       case 0x00: break;                                            // nop
       case 0x04: {                                                 // vsetvl  :156-159
         unsigned l;
         aloha_status s = vl_logn(imm, vp->max_logn, &l);
-        if (s) return fail(vp, s, "pc %u: vsetvl %#llx", pc, (u64)imm);
+        if (s) ALOHA_RUN_FAIL(s, "pc %u: vsetvl %#llx", pc, (u64)imm);
+        if (imm != vp->vl_bits) {                                  // aliases are sized by VL
+          ALOHA_RUN_CK(flush());
+          for (unsigned r = 0; r < ALOHA_NVREG; r++)
+            if (alias[r]) {
+              unsigned lo = 0;
+              if (vl_logn(vp->vl_bits, vp->max_logn, &lo) == ALOHA_OK)
+                HIPCK(vp, hipMemcpyAsync(vreg(vp, r), alias[r], (size_t)8 << lo, hipMemcpyDeviceToDevice, st));
+              alias[r] = nullptr;
+            }
+        }
         vp->vl_bits = imm;
         break;
       }
       case 0x08:                                                   // vsetq   :160-163
-        if (!modulus_ok(imm)) return fail(vp, ALOHA_ERR_MODULUS, "pc %u: vsetq %#llx", pc, (u64)imm);
+        if (!modulus_ok(imm)) ALOHA_RUN_FAIL(ALOHA_ERR_MODULUS, "pc %u: vsetq %#llx", pc, (u64)imm);
         vp->q = imm;
         break;
       case 0x0c: vp->mu = imm; break;                              // vsetiq  :164-167 (RTL Barrett constant; unused here)
-      case 0x01: case 0x05: case 0x09: {                           // vfqmul / vfqadd / vfqsub  :178-373
+      case 0x01: case 0x05: case 0x09: case 0x0d: case 0x11: {     // vfqmul/vfqadd/vfqsub :178-373, vfqmod :374-395, vcp :396-417
         aloha::k::EwOp op;
-        const u64 *a, *b = nullptr;
+        unsigned ra, rb = ALOHA_NVREG;
         uint64_t s = 0;
-        if (funct3 == 0) {
-          if (((vs1 ^ vs2) & 1) == 0) return fail(vp, ALOHA_ERR_BANK, "pc %u: .vv with v%u, v%u in one bank", pc, vs1, vs2);
-          a = vreg(vp, vs1); b = vreg(vp, vs2);
+        if (funct6 == 0x0d || funct6 == 0x11) {
+          ra = vs1; op = funct6 == 0x0d ? aloha::k::EW_MOD : aloha::k::EW_CP;
+        } else if (funct3 == 0) {
+          if (((vs1 ^ vs2) & 1) == 0) ALOHA_RUN_FAIL(ALOHA_ERR_BANK, "pc %u: .vv with v%u, v%u in one bank", pc, vs1, vs2);
+          ra = vs1; rb = vs2;
           op = funct6 == 0x01 ? aloha::k::EW_MUL_VV : funct6 == 0x05 ? aloha::k::EW_ADD_VV : aloha::k::EW_SUB_VV;
         } else if (funct3 == 1) {
-          a = vreg(vp, vs1); s = imm;
+          ra = vs1; s = imm;
           op = funct6 == 0x01 ? aloha::k::EW_MUL_VS : funct6 == 0x05 ? aloha::k::EW_ADD_VS : aloha::k::EW_SUB_VS;
         } else if (funct3 == 2 && funct6 == 0x09) {
-          a = vreg(vp, vs2); s = imm; op = aloha::k::EW_SUB_SV;
-        } else return fail(vp, ALOHA_ERR_DECODE, "pc %u: funct3 %u on funct6 %#x", pc, funct3, funct6);
+          ra = vs2; s = imm; op = aloha::k::EW_SUB_SV;
+        } else ALOHA_RUN_FAIL(ALOHA_ERR_DECODE, "pc %u: funct3 %u on funct6 %#x", pc, funct3, funct6);
         s = s >= q ? s - q : s;                                    // the scalar is normalised like a lane input (modalu.sv:46)
-        if (s >= q) return fail(vp, ALOHA_ERR_ARG, "pc %u: scalar operand %#llx >= 2q", pc, (u64)imm);
-        HIPCK(vp, aloha::k::ew(st, op, vreg(vp, vd), a, b, s, aloha::nt::shoup(s, q), modctx(q), n));
+        if (s >= q) ALOHA_RUN_FAIL(ALOHA_ERR_ARG, "pc %u: scalar operand %#llx >= 2q", pc, (u64)imm);
+        ALOHA_RUN_CK(flush());
+        const u64 *a = rd(ra), *b = rb < ALOHA_NVREG ? rd(rb) : nullptr;
+        u64 *z = nullptr, *dst = vreg(vp, vd);
+        ALOHA_RUN_CK(direct_store(&z));
+        // element-wise in place (z == a or z == b) is safe; a partial overlap is not
+        if (z && ((a != z && overlap(a, z, n)) || (b && b != z && overlap(b, z, n)))) z = nullptr;
+        if (z) {
+          ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
+          dst = z;
+        }
+        HIPCK(vp, aloha::k::ew(st, op, dst, a, b, s, aloha::nt::shoup(s, q), modctx(q), n));
         vp->stats.kernel_launches++;
+        alias[vd] = nullptr;
+        if (z) { pc++; vp->stats.instructions++; }                 // the vse is done
         break;
       }
-      case 0x0d: case 0x11:                                        // vfqmod :374-395, vcp :396-417
-        HIPCK(vp, aloha::k::ew(st, funct6 == 0x0d ? aloha::k::EW_MOD : aloha::k::EW_CP, vreg(vp, vd), vreg(vp, vs1),
-                               nullptr, 0, 0, modctx(q), n));
-        vp->stats.kernel_launches++;
-        break;
       case 0x15: case 0x19: {                                      // vaut / vroli  :460-501,:549-558
         const uint64_t k = (step + imm) & (n - 1);                 // scalar_iconn = csr_step + imm, kept mod N
                                                                    // (vxu_lane.sv:594, vxu_top_tb.sv:603)
-        u64 *dst = vreg(vp, vd);
-        const bool inplace = vd == vs1;
+        if (funct6 == 0x15 && !((step + imm) & 1))
+          ALOHA_RUN_FAIL(ALOHA_ERR_AUT, "pc %u: vaut with even exponent %llu", pc, (u64)(step + imm));
+        ALOHA_RUN_CK(flush());
+        const u64 *in = rd(vs1);
+        u64 *z = nullptr;
+        ALOHA_RUN_CK(direct_store(&z));
+        if (z && overlap(in, z, n)) z = nullptr;                   // a gather cannot run in place
+        if (z) ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
+        u64 *dst = z ? z : vreg(vp, vd);
+        const bool inplace = !z && in == dst;
         u64 *out = inplace ? vp->d_scratch : dst;
         if (funct6 == 0x15) {
-          if (!((step + imm) & 1)) return fail(vp, ALOHA_ERR_AUT, "pc %u: vaut with even exponent %llu", pc, (u64)(step + imm));
           uint64_t kinv = 1;                                       // k^-1 mod N by Newton iteration (k odd)
           for (int it = 0; it < 5; it++) kinv = kinv * (2 - k * kinv);
           kinv &= (n - 1);
-          HIPCK(vp, aloha::k::vaut(st, out, vreg(vp, vs1), logn, q, k, kinv));
+          HIPCK(vp, aloha::k::vaut(st, out, in, logn, q, k, kinv));
         } else {
-          HIPCK(vp, aloha::k::vroli(st, out, vreg(vp, vs1), logn, k));
+          HIPCK(vp, aloha::k::vroli(st, out, in, logn, k));
         }
         vp->stats.kernel_launches++;
         if (inplace) HIPCK(vp, hipMemcpyAsync(dst, out, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        alias[vd] = nullptr;
+        if (z) { pc++; vp->stats.instructions++; }
         break;
       }
       case 0x02: case 0x06: {                                      // vntt / vintt  :418-459
         uint32_t slot;
-        aloha_status s = get_slot(vp, q, logn, &slot);
-        if (s) return s;
+        ALOHA_RUN_CK(get_slot(vp, q, logn, &slot));
+        const bool inv = funct6 == 0x06;
         // The RTL ping-pongs between vs1 and vd once per stage (ntt_fsm.sv:80, vxu_lane.sv:315-318):
-        // vs1 is UNDEFINED afterwards; here it is simply left untouched.
+        // vs1 is UNDEFINED afterwards; here it keeps its value.
+        u64 *z = nullptr;
+        ALOHA_RUN_CK(direct_store(&z));
+        const u64 *src = rd(vs1);
+        if (z && src != z && overlap(src, z, n)) z = nullptr;
+        if (z) {
+          // fused `vle; vntt; vse`: join the pending batch unless it conflicts with it
+          bool conflict = !batch.empty() && (batch_inv != inv || batch_logn != logn);
+          for (const LimbJob &j : batch)
+            if (overlap(z, j.dst, n) || overlap(z, j.src, n) || overlap(src, j.dst, n)) conflict = true;
+          if (conflict) ALOHA_RUN_CK(flush());
+          if (alias[vs1] == src && dead_from(vp, pc + 2, vs1)) alias[vs1] = nullptr;   // (undefined after the transform anyway)
+          ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
+          batch.push_back(LimbJob{src, z, slot, 0});
+          batch_inv = inv; batch_logn = logn;
+          alias[vd] = nullptr;
+          pc++; vp->stats.instructions++;
+          break;
+        }
+        ALOHA_RUN_CK(flush());
         std::vector<LimbJob> job(1);
-        job[0] = LimbJob{vreg(vp, vs1), vreg(vp, vd), slot, 0};
-        s = run_transforms(vp, job, logn, funct6 == 0x06);
-        if (s) return s;
+        job[0] = LimbJob{src, vreg(vp, vd), slot, 0};
+        ALOHA_RUN_CK(run_transforms(vp, job, logn, inv));
+        alias[vd] = nullptr;
         break;
       }
       case 0x03: {                                                 // vle  :647-661,:681-686
         u64 *p = mem_rows(vp, imm, true, csr, n / kLanes);
-        if (!p) return fail(vp, ALOHA_ERR_ADDR, "pc %u: vle imm %#llx out of range", pc, (u64)imm);
+        if (!p) ALOHA_RUN_FAIL(ALOHA_ERR_ADDR, "pc %u: vle imm %#llx out of range", pc, (u64)imm);
+        if (fuse) { alias[vd] = p; break; }                        // zero copy: alias until either side is overwritten
         HIPCK(vp, hipMemcpyAsync(vreg(vp, vd), p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
         break;
       }
       case 0x07: {                                                 // vse (source register = vs1)  :502-523,:687-692
         u64 *p = mem_rows(vp, imm, false, csr, n / kLanes);
-        if (!p) return fail(vp, ALOHA_ERR_ADDR, "pc %u: vse imm %#llx out of range", pc, (u64)imm);
-        HIPCK(vp, hipMemcpyAsync(p, vreg(vp, vs1), (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        if (!p) ALOHA_RUN_FAIL(ALOHA_ERR_ADDR, "pc %u: vse imm %#llx out of range", pc, (u64)imm);
+        ALOHA_RUN_CK(flush());
+        const u64 *src = rd(vs1);
+        if (src == p) break;                                       // storing an alias back onto itself
+        if (overlap(src, p, n)) {                                  // shifted self-overlap: go through the register
+          HIPCK(vp, hipMemcpyAsync(vp->d_scratch, src, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+          src = vp->d_scratch;
+        }
+        ALOHA_RUN_CK(before_mem_write(p, n, pc + 1));
+        HIPCK(vp, hipMemcpyAsync(p, src, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
         break;
       }
       default:                                                     // RTL: silent no-op bundle (:524-532)
-        return fail(vp, ALOHA_ERR_DECODE, "pc %u: undefined funct6 %#x", pc, funct6);
+        ALOHA_RUN_FAIL(ALOHA_ERR_DECODE, "pc %u: undefined funct6 %#x", pc, funct6);
     }
   }
+#undef ALOHA_RUN_FAIL
+#undef ALOHA_RUN_CK
 }
+
+extern "C" {
 
 aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64_t src_row, uint32_t log_n,
                                const uint64_t *moduli, uint32_t count, int inverse) {

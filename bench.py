@@ -37,6 +37,19 @@ N = 1 << LOGN
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic_per_step(limbs: int):
+    """HBM bytes per step from the committed rocprofv3 PMC summary (FETCH_SIZE x2 per the guide's
+    gfx950 correction + WRITE_SIZE, separate --pmc passes of this same command), scaled to the
+    batch size; None when no summary is present."""
+    path = os.path.join(ROOT, "profiles", "r01_b_pmc_summary.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)["derived"]
+        return d["hbm_bytes_per_step_corrected"] * limbs / (d["algorithmic_bytes_per_step"] / (16 * N))
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds: float = 10.0) -> dict:
     import oracle
     q = oracle.nth_prime(LOGN, 0)
@@ -147,10 +160,11 @@ def main() -> int:
                        "log_n": LOGN, "limbs_per_gpu": B, "primes": L, "limbs_per_prime": P,
                        "kernels_per_step": launches // max(1, args.steps)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_per_step(B),
                          "note": "achieved = 16*N*B algorithmic bytes / device time of one step (both "
-                                 "tile kernels, HIP events on the engine's stream); ALU-bound regime: "
-                                 "see DESIGN.md"},
+                                 "tile kernels, HIP events on the engine's stream); traffic = HBM bytes "
+                                 "per step from profiles/r01_b_pmc_summary.json (two passes => 2.04x "
+                                 "algorithmic); see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
