@@ -1,0 +1,297 @@
+"""Rotate + hybrid key-switch for any number of RNS limbs, sharded by limb over GPUs.
+
+The reference ships one fixed program for two ciphertext primes and one special prime
+(``sim/vp/isram_file_generator/keyswitch.mem:1-122``): digit = one ciphertext
+prime, K = 1 special prime P, rounding mod-down.  This module issues the SAME algorithm, in the
+same HE-ISA and operand layout, for L limbs, with the intermediates streamed through SPM rows
+instead of the 32-entry register file, and with the limbs partitioned over ``world`` ranks
+(one process per GPU):
+
+    phase 1  per owned digit d :  D[d] = aut_k(iNTT(c1[d]));  R[d] = NTT(aut_k(iNTT(c0[d])))
+    exchange ALL-GATHER of the coefficient-form digits D[0..L-1]           (keyswitch.mem:4-43)
+    phase 2  per owned modulus j (ciphertext primes and P):
+                 acc_c[j] = sum_d NTT_j(D[d] mod m_j) * KSK[j][d][c]        (keyswitch.mem:46-79)
+    phase 3  owner of P       :  t_c = iNTT(acc_c[P]) + floor(P/2)          (keyswitch.mem:80-83)
+    exchange BROADCAST of t_0, t_1 from P's owner
+    phase 4  per owned j < L  :  r_c = (acc_c[j] - NTT_j(t_c - floor(P/2))) * P^-1
+                                 out_0[j] = R[j] + r_0,  out_1[j] = r_1      (keyswitch.mem:84-121)
+
+Every phase is an HE-ISA program run by the engine (``VP.run``); only the two exchanges go
+through ``torch.distributed`` (RCCL over xGMI on GPUs, gloo in the CPU tests).  With
+``world == 1`` this is the single-GPU key-switch for any L.
+
+Rank-local SPM layout, in limb slots of N/128 rows from ``base_row``:
+    CT_IN [2*Lr]  c0 of the owned primes, then c1        (Lr = owned ciphertext primes)
+    DIG   [G*Dr]  all digits, grouped by owner           (Dr = ceil(L/G); all-gather target)
+    ROT   [Lr]    rotated c0, NTT form
+    ACC   [2*Mr]  inner products of the owned moduli     (Mr = owned moduli incl. P if owned)
+    T     [2]     mod-down terms                         (broadcast target)
+    OUT   [2*Lr]  result: c0 then c1 of the owned primes
+Rank-local KSK layout: limb ((jl*L + d)*2 + c) for owned modulus jl, digit d, component c.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import isa
+from .programs import barrett_mu
+
+SPM, KSK = 0, 1
+LANES = 128
+
+
+def owner(j: int, world: int) -> int:
+    """Limb j (ciphertext primes 0..L-1, special prime = L) lives on rank j mod world."""
+    return j % world
+
+
+@dataclass
+class Layout:
+    n: int
+    moduli: Sequence[int]            # ciphertext primes q_0..q_{L-1}
+    special: int                     # P
+    world: int = 1
+    rank: int = 0
+    base_row: int = 0
+    owned_ct: List[int] = field(init=False)     # owned ciphertext-prime indices
+    owned_all: List[int] = field(init=False)    # owned modulus indices (L = special)
+
+    def __post_init__(self):
+        L = len(self.moduli)
+        self.owned_ct = [j for j in range(L) if owner(j, self.world) == self.rank]
+        self.owned_all = [j for j in range(L + 1) if owner(j, self.world) == self.rank]
+        self.L = L
+        self.rows = self.n // LANES
+        self.Lr = len(self.owned_ct)
+        self.Mr = len(self.owned_all)
+        self.Dr = -(-L // self.world)                       # digits per rank in the gather buffer
+        s = 0
+        self.ct_in = s; s += 2 * self.Lr
+        self.dig = s; s += self.world * self.Dr
+        self.rot = s; s += self.Lr
+        self.acc = s; s += 2 * self.Mr
+        self.t = s; s += 2
+        self.out = s; s += 2 * self.Lr
+        self.slots = s
+
+    # slot -> absolute row / byte offset helpers
+    def row(self, slot: int) -> int:
+        return self.base_row + slot * self.rows
+
+    def off(self, slot: int) -> int:
+        return self.row(slot) * 1024
+
+    def dig_slot(self, d: int) -> int:
+        return self.dig + owner(d, self.world) * self.Dr + d // self.world
+
+    def modulus(self, j: int) -> int:
+        return self.special if j == self.L else self.moduli[j]
+
+    @property
+    def spm_rows_needed(self) -> int:
+        return self.base_row + self.slots * self.rows
+
+    @property
+    def ksk_limbs(self) -> int:
+        return self.Mr * self.L * 2
+
+
+def _setq(q: int) -> List[str]:
+    return [f"vsetq {q:#x}", f"vsetiq {barrett_mu(q):#x}"]
+
+
+def program_digits(lo: Layout) -> List[str]:
+    """Phase 1.  c0 limb i at CT_IN[i], c1 limb i at CT_IN[Lr + i] (i = local index)."""
+    out = [f"vsetvl {64 * lo.n:#x}"]
+    for i, d in enumerate(lo.owned_ct):
+        out += _setq(lo.moduli[d])
+        out += [f"vle v0, abs+{lo.off(lo.ct_in + lo.Lr + i):#x}", "vintt v2, v0", "vaut v4, v2, 0x0",
+                f"vse v4, abs+{lo.off(lo.dig_slot(d)):#x}"]
+        out += [f"vle v0, abs+{lo.off(lo.ct_in + i):#x}", "vintt v2, v0", "vaut v0, v2, 0x0", "vntt v4, v0",
+                f"vse v4, abs+{lo.off(lo.rot + i):#x}"]
+    return out + ["break"]
+
+
+def program_inner(lo: Layout, jl: int) -> List[str]:
+    """Phase 2 for the jl-th owned modulus: both accumulators stay in registers over the digits."""
+    j = lo.owned_all[jl]
+    out = [f"vsetvl {64 * lo.n:#x}"] + _setq(lo.modulus(j))
+    for d in range(lo.L):
+        out += [f"vle v2, abs+{lo.off(lo.dig_slot(d)):#x}", "vfqmod v4, v2", "vntt v0, v4"]
+        for c in range(2):
+            acc = 6 + 2 * c                                     # v6, v8 (even bank)
+            out.append(f"vle v1, ksk+{((jl * lo.L + d) * 2 + c) * 8 * lo.n:#x}")
+            if d == 0:
+                out.append(f"vfqmul.vv v{acc}, v0, v1")
+            else:
+                out += ["vfqmul.vv v3, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v3"]
+    for c in range(2):
+        out.append(f"vse v{6 + 2 * c}, abs+{lo.off(lo.acc + 2 * jl + c):#x}")
+    return out + ["break"]
+
+
+def program_moddown_terms(lo: Layout) -> List[str]:
+    """Phase 3 (only on the rank that owns P)."""
+    jl = lo.owned_all.index(lo.L)
+    half = lo.special >> 1
+    out = [f"vsetvl {64 * lo.n:#x}"] + _setq(lo.special)
+    for c in range(2):
+        out += [f"vle v0, abs+{lo.off(lo.acc + 2 * jl + c):#x}", "vintt v2, v0", f"vfqadd.vs v2, v2, {half:#x}",
+                f"vse v2, abs+{lo.off(lo.t + c):#x}"]
+    return out + ["break"]
+
+
+def program_finish(lo: Layout) -> List[str]:
+    """Phase 4."""
+    half = lo.special >> 1
+    out = [f"vsetvl {64 * lo.n:#x}"]
+    for i, j in enumerate(lo.owned_ct):
+        q = lo.moduli[j]
+        pinv = pow(lo.special % q, q - 2, q)
+        jl = lo.owned_all.index(j)
+        out += _setq(q)
+        for c in range(2):
+            out += [f"vle v0, abs+{lo.off(lo.t + c):#x}", f"vfqsub.vs v2, v0, {half:#x}", "vntt v5, v2",
+                    f"vle v0, abs+{lo.off(lo.acc + 2 * jl + c):#x}", "vfqsub.vv v0, v0, v5",
+                    f"vfqmul.vs v0, v0, {pinv:#x}"]
+            if c == 0:
+                out += [f"vle v1, abs+{lo.off(lo.rot + i):#x}", "vfqadd.vv v0, v0, v1"]
+            out.append(f"vse v0, abs+{lo.off(lo.out + c * lo.Lr + i):#x}")
+    return out + ["break"]
+
+
+class Exchange:
+    """The two exchanges of the key-switch over ``torch.distributed`` (or a no-op for world 1).
+
+    ``tensor_of(vp, row, nwords)`` must return an int64 torch tensor VIEW of engine memory
+    (zero copy on the GPU, see ``device_tensor``); ``None`` selects the copy-in/copy-out
+    path through ``vp.read`` / ``vp.write`` used by the CPU tests."""
+
+    def __init__(self, group=None, tensor_of: Optional[Callable] = None, always: bool = False):
+        self.group = group
+        self.tensor_of = tensor_of
+        self.always = always          # run the collectives even for world == 1 (single-rank NCCL smoke test)
+
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self.group)
+
+    def all_gather_digits(self, vp, lo: Layout) -> None:
+        if lo.world == 1 and not self.always:
+            return
+        import torch
+        import torch.distributed as dist
+        chunk = lo.Dr * lo.n                                   # words contributed per rank
+        row0 = lo.row(lo.dig)
+        vp.sync()
+        if self.tensor_of is not None:
+            buf = self.tensor_of(vp, row0, lo.world * chunk)
+            dist.all_gather_into_tensor(buf, buf[lo.rank * chunk:(lo.rank + 1) * chunk].clone(), group=self.group)
+            torch.cuda.current_stream().synchronize()
+        else:
+            mine = torch.from_numpy(vp.read(SPM, row0 + lo.rank * lo.Dr * lo.rows, chunk).view(np.int64).copy())
+            parts = [torch.empty_like(mine) for _ in range(lo.world)]
+            dist.all_gather(parts, mine, group=self.group)
+            for r, p in enumerate(parts):
+                if r != lo.rank:
+                    vp.write(SPM, row0 + r * lo.Dr * lo.rows, p.numpy().view(np.uint64))
+
+    def broadcast_terms(self, vp, lo: Layout) -> None:
+        if lo.world == 1 and not self.always:
+            return
+        import torch
+        import torch.distributed as dist
+        src = owner(lo.L, lo.world)
+        row = lo.row(lo.t)
+        vp.sync()
+        if self.tensor_of is not None:
+            buf = self.tensor_of(vp, row, 2 * lo.n)
+            dist.broadcast(buf, src=dist.get_global_rank(self.group, src) if self.group is not None else src,
+                           group=self.group)
+            torch.cuda.current_stream().synchronize()
+        else:
+            t = torch.from_numpy(vp.read(SPM, row, 2 * lo.n).view(np.int64).copy())
+            dist.broadcast(t, src=src, group=self.group)
+            if lo.rank != src:
+                vp.write(SPM, row, t.numpy().view(np.uint64))
+
+
+def device_tensor(vp, row: int, nwords: int):
+    """int64 torch view of ``nwords`` words of the engine's SPM memory at ``row`` (zero copy)."""
+    import torch
+
+    class _Cai:
+        pass
+
+    c = _Cai()
+    c.__cuda_array_interface__ = {"shape": (nwords,), "typestr": "<i8", "data": (vp.device_ptr(SPM, row), False),
+                                  "version": 2}
+    return torch.as_tensor(c, device="cuda")
+
+
+class ShardedKeySwitch:
+    """Rotate + key-switch of one ciphertext whose limbs are sharded over ``world`` ranks."""
+
+    PC = 0
+
+    def __init__(self, vp, n: int, moduli: Sequence[int], special: int, world: int = 1, rank: int = 0,
+                 exchange: Optional[Exchange] = None, base_row: int = 0):
+        self.vp = vp
+        self.lo = Layout(n, list(moduli), special, world, rank, base_row)
+        self.ex = exchange or Exchange()
+        lo = self.lo
+        self._p_digits = isa.assemble("\n".join(program_digits(lo)))
+        self._p_inner = [isa.assemble("\n".join(program_inner(lo, jl))) for jl in range(lo.Mr)]
+        self._p_terms = isa.assemble("\n".join(program_moddown_terms(lo))) if lo.L in lo.owned_all else None
+        self._p_finish = isa.assemble("\n".join(program_finish(lo)))
+        for p in [self._p_digits, self._p_finish] + self._p_inner:
+            if len(p) > isa.IRAM_DEPTH:
+                raise ValueError("phase program exceeds the 4096-word instruction ROM")
+
+    # -- data placement -------------------------------------------------------------------------
+    def load_key(self, ksk_full: np.ndarray) -> None:
+        """``ksk_full``: the whole key, (L+1)*L*2 limbs ordered [modulus][digit][component]
+        (keyswitch.mem:46-77); only the owned moduli's limbs are kept on this rank."""
+        lo = self.lo
+        k = np.ascontiguousarray(ksk_full, dtype=np.uint64).reshape(lo.L + 1, lo.L * 2 * lo.n)
+        for jl, j in enumerate(lo.owned_all):
+            self.vp.write(KSK, jl * lo.L * 2 * lo.rows, k[j])
+
+    def load_ct(self, ct_full: np.ndarray) -> None:
+        """``ct_full``: 2*L limbs, c0 limbs then c1 limbs; the owned ones go to CT_IN."""
+        lo = self.lo
+        ct = np.ascontiguousarray(ct_full, dtype=np.uint64).reshape(2, lo.L, lo.n)
+        for c in range(2):
+            for i, j in enumerate(lo.owned_ct):
+                self.vp.write(SPM, lo.row(lo.ct_in + c * lo.Lr + i), ct[c, j])
+
+    def read_out(self) -> np.ndarray:
+        """Owned result limbs, shape (2, Lr, n)."""
+        lo = self.lo
+        self.vp.sync()
+        return self.vp.read(SPM, lo.row(lo.out), 2 * lo.Lr * lo.n).reshape(2, lo.Lr, lo.n)
+
+    # -- the op -----------------------------------------------------------------------------------
+    def _run(self, words, step: int = 0) -> None:
+        self.vp.load_isram(self.PC, words)
+        rc = self.vp.run(self.PC, src0=0, src1=0, rslt=0, ksk=0, step=step)
+        if rc:
+            raise RuntimeError(f"key-switch phase failed with status {rc}: {getattr(self.vp, 'last_error', '')}")
+
+    def rotate(self, k: int) -> None:
+        """Apply X -> X^k (k odd, reduced mod N by the engine like the reference) and switch
+        the key, reading CT_IN and writing OUT."""
+        lo = self.lo
+        if lo.Lr:
+            self._run(self._p_digits, step=k)
+        self.ex.all_gather_digits(self.vp, lo)
+        for words in self._p_inner:
+            self._run(words)
+        if self._p_terms is not None:
+            self._run(self._p_terms)
+        self.ex.broadcast_terms(self.vp, lo)
+        if lo.Lr:
+            self._run(self._p_finish)

@@ -1,0 +1,149 @@
+"""The general-L streamed key-switch programs and their limb-sharded (multi-GPU) orchestration.
+
+CPU tests: the compute engine is the oracle's ISA machine (tests may use the oracle as the
+checker/stand-in; the product engine needs a GPU), the exchange runs over gloo with two ranks.
+GPU test: the same orchestration on the real engine, single rank, N = 2^16.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from aloha_amd import isa, keyswitch, programs
+from util import N, P, Q0, Q1, load, manifest
+
+SPM, KSK = 0, 1
+
+
+def _random_case(n, L, seed):
+    logn = n.bit_length() - 1
+    mods = [oracle.nth_prime(logn, i) for i in range(L)]
+    special = oracle.nth_prime(logn, L)
+    rng = np.random.default_rng(seed)
+    ct = np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
+    ksk = np.stack([rng.integers(0, (mods + [special])[j], n, dtype=np.uint64)
+                    for j in range(L + 1) for _ in range(2 * L)])
+    return mods, special, ct, ksk
+
+
+def _single_rank(vp, n, mods, special, ct, ksk, k):
+    ks = keyswitch.ShardedKeySwitch(vp, n, mods, special)
+    ks.load_key(ksk)
+    ks.load_ct(ct)
+    ks.rotate(k)
+    return ks.read_out()
+
+
+def test_streamed_program_reproduces_golden_rotate():
+    """N = 8192, the reference's primes and key: the streamed L-limb program must give the
+    reference's own rotate result (tv/case0_4_4 kernel1, step 2 -> k = 3^2)."""
+    m = manifest()["case0"]
+    ct = load(m["kernel1_ct_before_rotate"]).reshape(4, N)
+    exp = load(m["kernel1_ct_after_rotate"]).reshape(2, 2, N)
+    vp = oracle.OracleVP()
+    got = _single_rank(vp, N, [Q0, Q1], P, ct, load(m["ksk_step2"]), pow(3, 2, 2 * N))
+    assert np.array_equal(got, exp)
+
+
+def test_streamed_program_equals_register_program():
+    """Own generators against each other on random data, L = 3 (both forms exist)."""
+    n, L = 1024, 3
+    mods, special, ct, ksk = _random_case(n, L, 5)
+    k = pow(3, 5, 2 * n)
+    got = _single_rank(oracle.OracleVP(spm_rows=4096, ksk_rows=4096), n, mods, special, ct, ksk, k)
+    vp = oracle.OracleVP(spm_rows=4096, ksk_rows=4096)
+    vp.load_isram(0, programs.assemble(programs.keyswitch(n, mods, special)))
+    rows = n // 128
+    vp.write(SPM, 0, ct.reshape(-1)); vp.write(KSK, 0, ksk.reshape(-1))
+    assert vp.run(0, src0=0, rslt=2 * L * rows, ksk=0, step=k) == 0
+    exp = vp.read(SPM, 2 * L * rows, 2 * L * n).reshape(2, L, n)
+    assert np.array_equal(got, exp)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, L, seed, k, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mods, special, ct, ksk = _random_case(n, L, seed)
+        vp = oracle.OracleVP(spm_rows=8192, ksk_rows=8192)
+        ks = keyswitch.ShardedKeySwitch(vp, n, mods, special, world=world, rank=rank,
+                                        exchange=keyswitch.Exchange(group=None, tensor_of=None))
+        ks.load_key(ksk); ks.load_ct(ct)
+        ks.rotate(k)
+        np.save(os.path.join(out_dir, f"out{rank}.npy"), ks.read_out())
+        np.save(os.path.join(out_dir, f"own{rank}.npy"), np.array(ks.lo.owned_ct))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("L", [4, 5])
+def test_two_rank_sharded_keyswitch_gloo(tmp_path, L):
+    """world_size 2 over gloo: limbs sharded j mod 2 (L = 5: uneven shards, P on rank 1),
+    all-gather of digits + broadcast of the mod-down terms; result == single-rank result."""
+    n, seed = 1024, 11
+    k = pow(3, 7, 2 * n)
+    mods, special, ct, ksk = _random_case(n, L, seed)
+    exp = _single_rank(oracle.OracleVP(spm_rows=8192, ksk_rows=8192), n, mods, special, ct, ksk, k)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, L, seed, k, str(tmp_path)), nprocs=2, join=True)
+    seen = set()
+    for r in range(2):
+        out = np.load(tmp_path / f"out{r}.npy")
+        own = np.load(tmp_path / f"own{r}.npy")
+        for i, j in enumerate(own):
+            assert np.array_equal(out[:, i], exp[:, j]), f"rank {r} limb {j}"
+            seen.add(int(j))
+    assert seen == set(range(L))
+
+
+def test_layout_partition_properties():
+    for world in (1, 2, 4, 8):
+        los = [keyswitch.Layout(1 << 16, [1] * 24, 2, world, r) for r in range(world)]
+        owned = sorted(j for lo in los for j in lo.owned_all)
+        assert owned == list(range(25))                       # every modulus exactly once
+        slots = sorted(lo.dig_slot(d) - lo.dig for lo in los[:1] for d in range(24))
+        assert len(set(slots)) == 24 and max(slots) < world * los[0].Dr
+        for lo in los:
+            assert lo.spm_rows_needed == lo.slots * 512
+
+
+@pytest.mark.gpu
+def test_streamed_keyswitch_on_gpu_n65536():
+    """BASELINE config 4/5 shape at reduced limb count: N = 2^16, L = 4 (+1), one GPU; and the
+    golden rotate through the streamed program on the GPU."""
+    from aloha_amd import vp as avp
+    n, L = 1 << 16, 4
+    mods, special, ct, ksk = _random_case(n, L, 21)
+    k = pow(3, 3, 2 * n)
+    lo = keyswitch.Layout(n, mods, special)
+    exp = _single_rank(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows), n, mods,
+                       special, ct, ksk, k)
+    with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
+        got = _single_rank(vp, n, mods, special, ct, ksk, k)
+        assert np.array_equal(got, exp)
+        # the RCCL exchange path (zero-copy int64 views of engine memory) with a one-rank group
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        try:
+            ks = keyswitch.ShardedKeySwitch(vp, n, mods, special, world=1, rank=0,
+                                            exchange=keyswitch.Exchange(tensor_of=keyswitch.device_tensor, always=True))
+            ks.load_key(ksk); ks.load_ct(ct)
+            ks.rotate(k)
+            assert np.array_equal(ks.read_out(), exp)
+        finally:
+            dist.destroy_process_group()
+    m = manifest()["case0"]
+    with avp.VP(spm_rows=1 << 14, ksk_rows=1 << 12, max_log_n=13) as vp:
+        got = _single_rank(vp, N, [Q0, Q1], P, load(m["kernel1_ct_before_rotate"]).reshape(4, N), load(m["ksk_step2"]),
+                           pow(3, 2, 2 * N))
+    assert np.array_equal(got, load(m["kernel1_ct_after_rotate"]).reshape(2, 2, N))
