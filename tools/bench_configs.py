@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Timings of BASELINE.json configs 2-5 on ONE GPU (the headline config is bench.py).
+
+    python tools/bench_configs.py > gpurun_out/configs.json
+
+Every workload is checked against the oracle on a sample before it is timed.  Numbers go to
+DESIGN.md section 6; they are not the headline metric.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import oracle  # noqa: E402  (checker only)
+from aloha_amd import isa, keyswitch, programs  # noqa: E402
+from aloha_amd import vp as avp  # noqa: E402
+
+SPM, KSK = 0, 1
+
+
+def timeit(fn, sync, reps):
+    fn(); sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def config2():
+    logn, n = 12, 1 << 12
+    q = avp.nth_prime(logn, 0)
+    rng = np.random.default_rng(2)
+    out = {}
+    with avp.VP(spm_rows=4096 * n // 128, ksk_rows=1, max_log_n=12) as vp:
+        a = rng.integers(0, q, n, dtype=np.uint64)
+        vp.write(SPM, 0, a)
+        vp.ntt_rows(SPM, n // 128, 0, logn, [q])
+        assert np.array_equal(vp.read(SPM, n // 128, n), oracle.ntt(a, q))
+        t1 = timeit(lambda: (vp.ntt_rows(SPM, 0, 0, logn, [q]), vp.sync()), vp.sync, 200)
+        out["single_ntt_latency_us"] = t1 * 1e6
+        B = 4096
+        mods = [q] * B
+        tb = timeit(lambda: vp.ntt_rows(SPM, 0, 0, logn, mods), vp.sync, 50)
+        out["batched_ntt_per_s"] = B / tb
+        out["batched_algorithmic_GBps"] = 16 * n * B / tb / 1e9
+    return out
+
+
+def config3():
+    logn, n, L = 14, 1 << 14, 8
+    rows = n // 128
+    mods = [avp.nth_prime(logn, i) for i in range(L)]
+    rng = np.random.default_rng(3)
+    a = np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in mods])
+    b = np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in mods])
+    with avp.VP(spm_rows=3 * L * rows, ksk_rows=1, max_log_n=14) as vp:
+        vp.write(SPM, 0, a.reshape(-1)); vp.write(SPM, L * rows, b.reshape(-1))
+        vp.load_isram(0, programs.assemble(programs.poly_mul(n, mods)))
+        run = lambda: vp.run(0, src0=0, src1=L * rows, rslt=2 * L * rows)
+        assert run() == 0
+        got = vp.read(SPM, 2 * L * rows, n)
+        fa, fb = oracle.ntt(a[0], mods[0]), oracle.ntt(b[0], mods[0])
+        prod = np.array([(int(x) * int(y)) % mods[0] for x, y in zip(fa, fb)], dtype=np.uint64)
+        assert np.array_equal(got, oracle.intt(prod, mods[0]))
+        t = timeit(run, vp.sync, 100)
+    return {"poly_mul_8_limbs_us": t * 1e6, "fused_min_GBps": 3 * 8 * n * L / t / 1e9,
+            "isa_materialised_GBps": 9 * 8 * n * L / t / 1e9}
+
+
+def config45(L):
+    logn, n = 16, 1 << 16
+    mods = [avp.nth_prime(logn, i) for i in range(L)]
+    special = avp.nth_prime(logn, L)
+    lo = keyswitch.Layout(n, mods, special)
+    rng = np.random.default_rng(4)
+    with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
+        ks = keyswitch.ShardedKeySwitch(vp, n, mods, special)
+        for jl in range(lo.Mr):                                  # random key, limb by limb (no 600 MB host array)
+            q = lo.modulus(jl)
+            vp.write(KSK, jl * L * 2 * lo.rows, rng.integers(0, q, L * 2 * n, dtype=np.uint64))
+        ct = np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
+        ks.load_ct(ct)
+        k = pow(3, 5, 2 * n)
+        ks.rotate(k); vp.sync()
+        t = timeit(lambda: ks.rotate(k), vp.sync, 5)
+        st = vp.stats()
+        transforms = L + L * (L + 1) + L + 2 * (1 + L)
+    return {"L": L, "rotate_keyswitch_ms": t * 1e3, "transforms_per_rotate": transforms,
+            "transform_equiv_per_s": transforms / t, "kernel_launches_total": st["kernel_launches"]}
+
+
+def aut_batch():
+    logn, n, B = 16, 1 << 16, 64
+    q = avp.nth_prime(logn, 0)
+    rows = n // 128
+    lines = [f"vsetvl {64 * n:#x}", f"vsetq {q:#x}"]
+    for i in range(B):
+        lines += [f"vle v0, src0+{i * 8 * n:#x}", "vaut v2, v0, 0x0", f"vse v2, rslt+{i * 8 * n:#x}"]
+    words = isa.assemble("\n".join(lines + ["break"]))
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, q, B * n, dtype=np.uint64)
+    with avp.VP(spm_rows=2 * B * rows, ksk_rows=1, max_log_n=16) as vp:
+        vp.write(SPM, 0, a)
+        vp.load_isram(0, words)
+        run = lambda: vp.run(0, src0=0, rslt=B * rows, step=pow(3, 7, 2 * n))
+        assert run() == 0
+        assert np.array_equal(vp.read(SPM, B * rows, n), oracle.vaut(a[:n], q, pow(3, 7, 2 * n)))
+        t = timeit(run, vp.sync, 20)
+    return {"limbs": B, "us_per_limb": t / B * 1e6, "algorithmic_GBps": 16 * n * B / t / 1e9}
+
+
+if __name__ == "__main__":
+    res = {"config2_ntt_n4096": config2(), "config3_polymul_n16384_8limbs": config3(),
+           "config4_keyswitch_n65536_L24": config45(24), "config5_keyswitch_n65536_L32": config45(32),
+           "config5_automorphism_batch": aut_batch()}
+    print(json.dumps(res, indent=1))
