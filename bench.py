@@ -70,8 +70,8 @@ def cpu_baseline(seconds: float = 10.0) -> dict:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--primes", type=int, default=32)
     ap.add_argument("--polys", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
