@@ -66,6 +66,64 @@ __global__ __launch_bounds__(256) void vroli_kernel(u64 *__restrict__ out, const
     out[j] = in[(j + s) & (n - 1)];
 }
 
+// ---- batched forms: blockIdx.y selects the job, so every branch below is block-uniform ---------
+__global__ __launch_bounds__(256) void ew_batch_kernel(const EwJob *__restrict__ jobs, uint32_t n2) {
+  const EwJob jb = jobs[blockIdx.y];
+  u64x2 *d = reinterpret_cast<u64x2 *>(jb.d);
+  const u64x2 *a = reinterpret_cast<const u64x2 *>(jb.a);
+  const u64x2 *b = reinterpret_cast<const u64x2 *>(jb.b);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+    const u64x2 va = a[i];
+    u64x2 vb{0, 0}, r;
+#define ALOHA_EW_BODY(OPC, VV)                                              \
+  case OPC:                                                                  \
+    if (VV) vb = b[i];                                                       \
+    r.x = ew_one<OPC>(va.x, vb.x, jb.s, jb.s_shoup, jb.m);                    \
+    r.y = ew_one<OPC>(va.y, vb.y, jb.s, jb.s_shoup, jb.m);                    \
+    break;
+    switch (jb.op) {
+      ALOHA_EW_BODY(EW_MUL_VV, true) ALOHA_EW_BODY(EW_MUL_VS, false) ALOHA_EW_BODY(EW_ADD_VV, true)
+      ALOHA_EW_BODY(EW_ADD_VS, false) ALOHA_EW_BODY(EW_SUB_VV, true) ALOHA_EW_BODY(EW_SUB_VS, false)
+      ALOHA_EW_BODY(EW_SUB_SV, false) ALOHA_EW_BODY(EW_MOD, false) ALOHA_EW_BODY(EW_CP, false)
+      default: r = va; break;
+    }
+#undef ALOHA_EW_BODY
+    d[i] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void aut_batch_kernel(const AutJob *__restrict__ jobs, uint32_t n) {
+  const AutJob jb = jobs[blockIdx.y];
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+    if (jb.roll) {
+      jb.out[j] = jb.in[(j + jb.k) & (n - 1)];
+    } else {
+      const uint32_t i = (j * jb.k_inv) & (n - 1);
+      const uint32_t t = (i * jb.k) & (2 * n - 1);
+      const u64 v = jb.in[i];
+      jb.out[j] = (t >= n) ? jb.q - v : v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dot_kernel(DotArgs g, uint32_t n2) {
+  const u64 q = g.m.q, mu = g.m.mu;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+    u64x2 acc{0, 0};
+    if (g.init) {
+      acc = reinterpret_cast<const u64x2 *>(g.init)[i];
+      acc.x = csub(acc.x, q); acc.y = csub(acc.y, q);
+    }
+    for (int t = 0; t < g.nterms; t++) {
+      const u64x2 va = reinterpret_cast<const u64x2 *>(g.a[t])[i];
+      const u64x2 vb = reinterpret_cast<const u64x2 *>(g.b[t])[i];
+      acc.x = addmod(acc.x, mulmod_barrett(csub(va.x, q), csub(vb.x, q), q, mu), q);
+      acc.y = addmod(acc.y, mulmod_barrett(csub(va.y, q), csub(vb.y, q), q, mu), q);
+    }
+    reinterpret_cast<u64x2 *>(g.d)[i] = acc;
+  }
+}
+
 inline uint32_t grid_for(uint32_t work_items) {
   uint32_t g = (work_items + 255) / 256;
   return g > 2048 ? 2048 : (g ? g : 1);
@@ -89,6 +147,30 @@ hipError_t ew(hipStream_t st, EwOp op, u64 *d, const u64 *a, const u64 *b, u64 s
 #undef ALOHA_EW_CASE
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t ew_batch(hipStream_t st, const EwJob *d_jobs, uint32_t njobs, uint32_t n) {
+  if (!njobs) return hipSuccess;
+  const uint32_t n2 = n / 2;
+  uint32_t gx = grid_for(n2);
+  if (njobs >= 64 && gx > 32) gx = 32;             // enough blocks already: keep per-job grids short
+  hipLaunchKernelGGL(ew_batch_kernel, dim3(gx, njobs), dim3(256), 0, st, d_jobs, n2);
+  return hipGetLastError();
+}
+
+hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsigned logn) {
+  if (!njobs) return hipSuccess;
+  const uint32_t n = 1u << logn;
+  uint32_t gx = grid_for(n);
+  if (njobs >= 64 && gx > 64) gx = 64;
+  hipLaunchKernelGGL(aut_batch_kernel, dim3(gx, njobs), dim3(256), 0, st, d_jobs, n);
+  return hipGetLastError();
+}
+
+hipError_t dot(hipStream_t st, const DotArgs &args, uint32_t n) {
+  const uint32_t n2 = n / 2;
+  hipLaunchKernelGGL(dot_kernel, dim3(grid_for(n2)), dim3(256), 0, st, args, n2);
   return hipGetLastError();
 }
 

@@ -33,6 +33,36 @@ hipError_t vaut(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 q, u
 // cyclic roll: out[j] = in[(j + s) mod N]  (vxu_lane.sv:595,:597)
 hipError_t vroli(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 s);
 
+// ---- batched forms used by the fusing sequencer (one launch for many limbs) ----------------------
+struct EwJob {             // d = op(a, b | s) on n words under modulus m
+  u64 *d;
+  const u64 *a, *b;
+  u64 s, s_shoup;
+  ModCtx m;
+  int op, pad;
+};
+struct AutJob {            // roll == 0: automorphism gather with (k, k_inv); roll == 1: cyclic roll by k
+  u64 *out;
+  const u64 *in;
+  u64 q;
+  uint32_t k, k_inv, roll, pad;
+};
+hipError_t ew_batch(hipStream_t st, const EwJob *d_jobs, uint32_t njobs, uint32_t n);
+hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsigned logn);
+
+// d = init + sum_t a[t] .* b[t]  (mod q), up to kDotTerms terms per launch: the key-switch
+// inner product (keyswitch.mem:46-79) as ONE pass over its operands.
+constexpr int kDotTerms = 32;
+struct DotArgs {
+  const u64 *a[kDotTerms];
+  const u64 *b[kDotTerms];
+  const u64 *init;         // may be null
+  u64 *d;
+  ModCtx m;
+  int nterms, pad;
+};
+hipError_t dot(hipStream_t st, const DotArgs &args, uint32_t n);
+
 // ---- transforms --------------------------------------------------------------------------
 // Device-resident twiddle set of one (q, N); tables hold (w, floor(w*2^64/q)) pairs.
 struct TwiddleDev {

@@ -92,6 +92,7 @@ struct aloha_vp {
   // batched transforms
   std::vector<std::unique_ptr<TransformPlan>> plans;
   std::vector<RowsKey> rows_cache;
+  std::vector<std::pair<std::vector<uint8_t>, void *>> blobs;   // cached device copies of batched job arrays
   uint32_t chunk_limbs = 0;      // limbs per chunk of a batched transform (0 = whole batch; chunking did not pay)
   aloha_vp_stats stats{};
   std::string err;
@@ -351,6 +352,7 @@ void aloha_vp_destroy(aloha_vp *vp) {
   if (vp->d_scratch) (void)hipFree(vp->d_scratch);
   if (vp->d_primes) (void)hipFree(vp->d_primes);
   vp->plans.clear();
+  for (auto &b : vp->blobs) if (b.second) (void)hipFree(b.second);
   if (vp->own_stream && vp->stream) (void)hipStreamDestroy(vp->stream);
   delete vp;
 }
@@ -484,6 +486,24 @@ bool dead_from(const aloha_vp *vp, uint32_t pc, unsigned r) {
 
 inline bool overlap(const u64 *a, const u64 *b, size_t n) { return a < b + n && b < a + n; }
 
+// Device copy of a job array, cached by content: programs repeat, so in steady state a batched
+// launch needs no upload.  Entries are immutable; eviction happens only after a stream sync.
+aloha_status device_blob(aloha_vp *vp, const void *host, size_t bytes, const void **dev) {
+  for (auto &b : vp->blobs)
+    if (b.first.size() == bytes && memcmp(b.first.data(), host, bytes) == 0) { *dev = b.second; return ALOHA_OK; }
+  void *d = nullptr;
+  HIPCK(vp, hipMalloc(&d, bytes));
+  HIPCK(vp, hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  if (vp->blobs.size() >= 512) {                             // everything queued has drained (sync above)
+    (void)hipFree(vp->blobs.front().second);
+    vp->blobs.erase(vp->blobs.begin());
+  }
+  vp->blobs.emplace_back(std::vector<uint8_t>((const uint8_t *)host, (const uint8_t *)host + bytes), d);
+  *dev = d;
+  return ALOHA_OK;
+}
+
 }  // namespace
 
 extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
@@ -493,21 +513,85 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   hipStream_t st = vp->stream;
   const bool fuse = !(vp->flags & ALOHA_FLAG_NO_FUSION);
   const u64 *alias[ALOHA_NVREG] = {nullptr};                // non-null: the register's value is memory at this address
-  std::vector<LimbJob> batch;                               // pending fused transforms
+  // Pending batch: deferred memory-to-memory jobs of ONE kind, launched together by flush().
+  enum { PK_NONE, PK_NTT, PK_AUT, PK_EW } pend_kind = PK_NONE;
+  std::vector<LimbJob> batch;                               // PK_NTT
+  std::vector<aloha::k::AutJob> aut_batch;                  // PK_AUT
+  std::vector<aloha::k::EwJob> ew_batch;                    // PK_EW
+  std::vector<std::pair<const u64 *, const u64 *>> pend_rw; // (read range, written range) of every pending job
   bool batch_inv = false;
   unsigned batch_logn = 0;
+  // Lazy dot products: register r stands for sum_t a_t .* b_t (mod lazy_q[r]) over memory
+  // operands -- the key-switch inner product (keyswitch.mem:46-79) evaluated in one pass.
+  std::vector<std::pair<const u64 *, const u64 *>> lazy[ALOHA_NVREG];
+  uint64_t lazy_q[ALOHA_NVREG] = {0};
 
   auto rd = [&](unsigned r) -> const u64 * { return alias[r] ? alias[r] : vreg(vp, r); };
   auto flush = [&]() -> aloha_status {
-    if (batch.empty()) return ALOHA_OK;
-    aloha_status s = run_transforms(vp, batch, batch_logn, batch_inv);
-    batch.clear();
+    aloha_status s = ALOHA_OK;
+    if (pend_kind == PK_NTT && !batch.empty()) {
+      s = run_transforms(vp, batch, batch_logn, batch_inv);
+    } else if (pend_kind == PK_AUT && !aut_batch.empty()) {
+      const void *dj = nullptr;
+      s = device_blob(vp, aut_batch.data(), aut_batch.size() * sizeof(aut_batch[0]), &dj);
+      if (!s) {
+        hipError_t e = aloha::k::aut_batch(st, (const aloha::k::AutJob *)dj, (uint32_t)aut_batch.size(), batch_logn);
+        vp->stats.kernel_launches++;
+        if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "aut_batch: %s", hipGetErrorString(e));
+      }
+    } else if (pend_kind == PK_EW && !ew_batch.empty()) {
+      const void *dj = nullptr;
+      s = device_blob(vp, ew_batch.data(), ew_batch.size() * sizeof(ew_batch[0]), &dj);
+      if (!s) {
+        hipError_t e = aloha::k::ew_batch(st, (const aloha::k::EwJob *)dj, (uint32_t)ew_batch.size(), 1u << batch_logn);
+        vp->stats.kernel_launches++;
+        if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "ew_batch: %s", hipGetErrorString(e));
+      }
+    }
+    batch.clear(); aut_batch.clear(); ew_batch.clear(); pend_rw.clear();
+    pend_kind = PK_NONE;
     return s;
   };
+  // may a job that reads [a..), [b..) and writes [z..) join the pending batch of `kind`?
+  auto can_join = [&](int kind, unsigned logn_, const u64 *a, const u64 *b, const u64 *z, size_t n) -> bool {
+    if (pend_kind == PK_NONE) return true;
+    if (pend_kind != kind || batch_logn != logn_) return false;
+    for (const auto &rw : pend_rw) {
+      const u64 *r = rw.first, *w = rw.second;
+      if (overlap(z, w, n) || (r && overlap(z, r, n))) return false;          // WAW / WAR
+      if ((a && overlap(a, w, n)) || (b && overlap(b, w, n))) return false;    // RAW
+    }
+    return true;
+  };
+  // evaluate a lazy dot product into dst (the register's own storage by default)
+  auto materialise = [&](unsigned r, u64 *dst, uint32_t n) -> aloha_status {
+    if (lazy[r].empty()) return ALOHA_OK;
+    aloha_status s = flush();                                 // its operands may be outputs of pending jobs
+    if (s) return s;
+    if (!dst) dst = vreg(vp, r);
+    const u64 *init = nullptr;
+    for (size_t t0 = 0; t0 < lazy[r].size(); t0 += aloha::k::kDotTerms) {
+      aloha::k::DotArgs g{};
+      g.nterms = (int)std::min<size_t>(aloha::k::kDotTerms, lazy[r].size() - t0);
+      for (int t = 0; t < g.nterms; t++) { g.a[t] = lazy[r][t0 + t].first; g.b[t] = lazy[r][t0 + t].second; }
+      g.init = init; g.d = dst; g.m = modctx(lazy_q[r]);
+      HIPCK(vp, aloha::k::dot(st, g, n));
+      vp->stats.kernel_launches++;
+      init = dst;
+    }
+    lazy[r].clear();
+    return ALOHA_OK;
+  };
   // Memory [dst, dst+n) is about to be written at next_pc-1: registers aliasing it either die
-  // (dropped) or get their value copied out first.
+  // (dropped) or get their value copied out first; lazy dot products over it are evaluated.
   auto before_mem_write = [&](const u64 *dst, size_t n, uint32_t next_pc) -> aloha_status {
     for (unsigned r = 0; r < ALOHA_NVREG; r++) {
+      for (const auto &t : lazy[r])
+        if (overlap(t.first, dst, n) || overlap(t.second, dst, n)) {
+          if (dead_from(vp, next_pc, r)) lazy[r].clear();
+          else { aloha_status s = materialise(r, nullptr, (uint32_t)n); if (s) return s; }
+          break;
+        }
       if (!alias[r] || !overlap(alias[r], dst, n)) continue;
       if (!dead_from(vp, next_pc, r)) {
         aloha_status s = flush();                            // the copy must see memory as of program order
@@ -550,6 +634,17 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       return ALOHA_OK;
     };
 
+    // Lazy dot products: the accumulate pattern `vfqmul.vv t, a, b ; vfqadd.vv acc, acc, t` folds
+    // (below); any other read of a lazy register evaluates it first, any overwrite drops it.
+    const bool fold_add = fuse && funct6 == 0x05 && funct3 == 0 && ((vs1 ^ vs2) & 1) && (vd == vs1 || vd == vs2) &&
+                          !lazy[vs1].empty() && !lazy[vs2].empty() && lazy_q[vs1] == q && lazy_q[vs2] == q &&
+                          dead_from(vp, pc + 1, vd == vs1 ? vs2 : vs1);
+    if (!is_cfg && !fold_add) {
+      const bool lazy_store = funct6 == 0x07 && !lazy[vs1].empty() && dead_from(vp, pc + 1, vs1);
+      for (unsigned r = 0; r < ALOHA_NVREG; r++)
+        if (!lazy[r].empty() && reads_reg(d, r) && !lazy_store) ALOHA_RUN_CK(materialise(r, nullptr, n));
+    }
+
     switch (funct6) {
       case 0x10: return flush();                                   // break   expander.v:141-151
       case 0x00: break;                                            // nop
@@ -557,8 +652,12 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         unsigned l;
         aloha_status s = vl_logn(imm, vp->max_logn, &l);
         if (s) ALOHA_RUN_FAIL(s, "pc %u: vsetvl %#llx", pc, (u64)imm);
-        if (imm != vp->vl_bits) {                                  // aliases are sized by VL
+        if (imm != vp->vl_bits) {                                  // aliases and lazy values are sized by VL
           ALOHA_RUN_CK(flush());
+          unsigned lo0 = 0;
+          if (vl_logn(vp->vl_bits, vp->max_logn, &lo0) == ALOHA_OK)
+            for (unsigned r = 0; r < ALOHA_NVREG; r++) ALOHA_RUN_CK(materialise(r, nullptr, 1u << lo0));
+          for (unsigned r = 0; r < ALOHA_NVREG; r++) lazy[r].clear();
           for (unsigned r = 0; r < ALOHA_NVREG; r++)
             if (alias[r]) {
               unsigned lo = 0;
@@ -593,20 +692,44 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         } else ALOHA_RUN_FAIL(ALOHA_ERR_DECODE, "pc %u: funct3 %u on funct6 %#x", pc, funct3, funct6);
         s = s >= q ? s - q : s;                                    // the scalar is normalised like a lane input (modalu.sv:46)
         if (s >= q) ALOHA_RUN_FAIL(ALOHA_ERR_ARG, "pc %u: scalar operand %#llx >= 2q", pc, (u64)imm);
-        ALOHA_RUN_CK(flush());
+        if (fold_add) {                                            // acc += t  with both sides lazy: concatenate the sums
+          const unsigned t = vd == vs1 ? vs2 : vs1;
+          lazy[vd].insert(lazy[vd].end(), lazy[t].begin(), lazy[t].end());
+          lazy[t].clear();
+          break;
+        }
         const u64 *a = rd(ra), *b = rb < ALOHA_NVREG ? rd(rb) : nullptr;
         u64 *z = nullptr, *dst = vreg(vp, vd);
         ALOHA_RUN_CK(direct_store(&z));
         // element-wise in place (z == a or z == b) is safe; a partial overlap is not
         if (z && ((a != z && overlap(a, z, n)) || (b && b != z && overlap(b, z, n)))) z = nullptr;
-        if (z) {
-          ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
-          dst = z;
+        if (fuse && !z && op == aloha::k::EW_MUL_VV && alias[ra] && alias[rb]) {
+          // product of two memory operands kept in a register: start a lazy dot product
+          lazy[vd].assign(1, std::make_pair(a, b));
+          lazy_q[vd] = q;
+          alias[vd] = nullptr;
+          break;
         }
+        lazy[vd].clear();
+        if (z) {
+          // deferred: joins the pending element-wise batch (one launch for many limbs)
+          if (!can_join(PK_EW, logn, a, b, z, n)) ALOHA_RUN_CK(flush());
+          ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
+          if (!can_join(PK_EW, logn, a, b, z, n)) ALOHA_RUN_CK(flush());      // (before_mem_write may have changed nothing; cheap)
+          aloha::k::EwJob jb{};
+          jb.d = z; jb.a = a; jb.b = b ? b : a; jb.s = s; jb.s_shoup = aloha::nt::shoup(s, q); jb.m = modctx(q); jb.op = (int)op;
+          ew_batch.push_back(jb);
+          pend_rw.emplace_back(a, z);
+          if (b) pend_rw.emplace_back(b, z);
+          pend_kind = PK_EW; batch_logn = logn;
+          alias[vd] = nullptr;
+          pc++; vp->stats.instructions++;                          // the vse is done
+          break;
+        }
+        ALOHA_RUN_CK(flush());
         HIPCK(vp, aloha::k::ew(st, op, dst, a, b, s, aloha::nt::shoup(s, q), modctx(q), n));
         vp->stats.kernel_launches++;
         alias[vd] = nullptr;
-        if (z) { pc++; vp->stats.instructions++; }                 // the vse is done
         break;
       }
       case 0x15: case 0x19: {                                      // vaut / vroli  :460-501,:549-558
@@ -614,13 +737,32 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
                                                                    // (vxu_lane.sv:594, vxu_top_tb.sv:603)
         if (funct6 == 0x15 && !((step + imm) & 1))
           ALOHA_RUN_FAIL(ALOHA_ERR_AUT, "pc %u: vaut with even exponent %llu", pc, (u64)(step + imm));
-        ALOHA_RUN_CK(flush());
         const u64 *in = rd(vs1);
         u64 *z = nullptr;
         ALOHA_RUN_CK(direct_store(&z));
         if (z && overlap(in, z, n)) z = nullptr;                   // a gather cannot run in place
-        if (z) ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
-        u64 *dst = z ? z : vreg(vp, vd);
+        lazy[vd].clear();
+        if (z) {
+          // deferred: joins the pending permutation batch
+          if (!can_join(PK_AUT, logn, in, nullptr, z, n)) ALOHA_RUN_CK(flush());
+          ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
+          if (!can_join(PK_AUT, logn, in, nullptr, z, n)) ALOHA_RUN_CK(flush());
+          aloha::k::AutJob jb{};
+          jb.out = z; jb.in = in; jb.q = q; jb.k = (uint32_t)k; jb.roll = funct6 == 0x19;
+          if (!jb.roll) {
+            uint64_t kinv = 1;                                     // k^-1 mod N by Newton iteration (k odd)
+            for (int it = 0; it < 5; it++) kinv = kinv * (2 - k * kinv);
+            jb.k_inv = (uint32_t)(kinv & (n - 1));
+          }
+          aut_batch.push_back(jb);
+          pend_rw.emplace_back(in, z);
+          pend_kind = PK_AUT; batch_logn = logn;
+          alias[vd] = nullptr;
+          pc++; vp->stats.instructions++;
+          break;
+        }
+        ALOHA_RUN_CK(flush());
+        u64 *dst = vreg(vp, vd);
         const bool inplace = !z && in == dst;
         u64 *out = inplace ? vp->d_scratch : dst;
         if (funct6 == 0x15) {
@@ -634,7 +776,6 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         vp->stats.kernel_launches++;
         if (inplace) HIPCK(vp, hipMemcpyAsync(dst, out, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
         alias[vd] = nullptr;
-        if (z) { pc++; vp->stats.instructions++; }
         break;
       }
       case 0x02: case 0x06: {                                      // vntt / vintt  :418-459
@@ -647,16 +788,18 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         ALOHA_RUN_CK(direct_store(&z));
         const u64 *src = rd(vs1);
         if (z && src != z && overlap(src, z, n)) z = nullptr;
+        lazy[vd].clear();
         if (z) {
-          // fused `vle; vntt; vse`: join the pending batch unless it conflicts with it
-          bool conflict = !batch.empty() && (batch_inv != inv || batch_logn != logn);
-          for (const LimbJob &j : batch)
-            if (overlap(z, j.dst, n) || overlap(z, j.src, n) || overlap(src, j.dst, n)) conflict = true;
-          if (conflict) ALOHA_RUN_CK(flush());
+          // fused `vle; vntt; vse`: join the pending transform batch unless it conflicts with it
+          // (an in-place job, src == z, is fine: can_join sees only OTHER jobs' ranges)
+          auto joinable = [&]() { return can_join(PK_NTT, logn, src, nullptr, z, n) && (batch.empty() || batch_inv == inv); };
+          if (!joinable()) ALOHA_RUN_CK(flush());
           if (alias[vs1] == src && dead_from(vp, pc + 2, vs1)) alias[vs1] = nullptr;   // (undefined after the transform anyway)
           ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
+          if (!joinable()) ALOHA_RUN_CK(flush());
           batch.push_back(LimbJob{src, z, slot, 0});
-          batch_inv = inv; batch_logn = logn;
+          pend_rw.emplace_back(src, z);
+          pend_kind = PK_NTT; batch_inv = inv; batch_logn = logn;
           alias[vd] = nullptr;
           pc++; vp->stats.instructions++;
           break;
@@ -671,6 +814,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       case 0x03: {                                                 // vle  :647-661,:681-686
         u64 *p = mem_rows(vp, imm, true, csr, n / kLanes);
         if (!p) ALOHA_RUN_FAIL(ALOHA_ERR_ADDR, "pc %u: vle imm %#llx out of range", pc, (u64)imm);
+        lazy[vd].clear();
         if (fuse) { alias[vd] = p; break; }                        // zero copy: alias until either side is overwritten
         HIPCK(vp, hipMemcpyAsync(vreg(vp, vd), p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
         break;
@@ -678,6 +822,19 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       case 0x07: {                                                 // vse (source register = vs1)  :502-523,:687-692
         u64 *p = mem_rows(vp, imm, false, csr, n / kLanes);
         if (!p) ALOHA_RUN_FAIL(ALOHA_ERR_ADDR, "pc %u: vse imm %#llx out of range", pc, (u64)imm);
+        if (!lazy[vs1].empty()) {                                  // (only reached when vs1 is dead afterwards)
+          bool clash = false;                                      // the sum must not read what it overwrites
+          for (const auto &t : lazy[vs1]) clash |= overlap(t.first, p, n) || overlap(t.second, p, n);
+          if (!clash) {
+            std::vector<std::pair<const u64 *, const u64 *>> terms;
+            terms.swap(lazy[vs1]);                                 // keep before_mem_write from evaluating it twice
+            ALOHA_RUN_CK(before_mem_write(p, n, pc + 1));
+            lazy[vs1].swap(terms);
+            ALOHA_RUN_CK(materialise(vs1, p, n));                  // the dot product lands in memory directly
+            break;
+          }
+          ALOHA_RUN_CK(materialise(vs1, nullptr, n));
+        }
         ALOHA_RUN_CK(flush());
         const u64 *src = rd(vs1);
         if (src == p) break;                                       // storing an alias back onto itself

@@ -20,6 +20,19 @@ Every phase is an HE-ISA program run by the engine (``VP.run``); only the two ex
 through ``torch.distributed`` (RCCL over xGMI on GPUs, gloo in the CPU tests).  With
 ``world == 1`` this is the single-GPU key-switch for any L.
 
+The programs are written loop by loop -- all transforms of a phase, then all permutations,
+then the element-wise steps -- so that the engine's fusing sequencer turns each loop into ONE
+batched launch (``vle; vntt; vse`` runs, ``vle; vaut; vse`` runs, ``vle; vle; op; vse`` runs)
+and the digit-by-key inner product into one pass per accumulator (``vfqmul.vv`` /
+``vfqadd.vv`` chains over memory operands).  The instruction semantics are the plain
+sequential ones; an engine without fusion (or the oracle) computes the same bytes.
+
+Where the reference writes ``vcp`` / ``vfqmod`` before a ``vntt`` to re-interpret a digit under
+another modulus (keyswitch.mem:9,13,29,33) these programs transform the loaded digit directly:
+the copy exists in the reference because ``vntt`` destroys its source register, and the
+butterfly's operand normalisation (modalu.sv:44-46) performs the same single conditional
+subtraction.
+
 Rank-local SPM layout, in limb slots of N/128 rows from ``base_row``:
     CT_IN [2*Lr]  c0 of the owned primes, then c1        (Lr = owned ciphertext primes)
     DIG   [G*Dr]  all digits, grouped by owner           (Dr = ceil(L/G); all-gather target)
@@ -27,6 +40,8 @@ Rank-local SPM layout, in limb slots of N/128 rows from ``base_row``:
     ACC   [2*Mr]  inner products of the owned moduli     (Mr = owned moduli incl. P if owned)
     T     [2]     mod-down terms                         (broadcast target)
     OUT   [2*Lr]  result: c0 then c1 of the owned primes
+    S1/S2 [2*Lr]  scratch (phase 1: coefficient forms; phase 4: mod-down intermediates)
+    SD    [L]     scratch (phase 2: digits in NTT form under the current modulus)
 Rank-local KSK layout: limb ((jl*L + d)*2 + c) for owned modulus jl, digit d, component c.
 """
 from __future__ import annotations
@@ -75,6 +90,9 @@ class Layout:
         self.acc = s; s += 2 * self.Mr
         self.t = s; s += 2
         self.out = s; s += 2 * self.Lr
+        self.s1 = s; s += 2 * self.Lr
+        self.s2 = s; s += 2 * self.Lr
+        self.sd = s; s += L
         self.slots = s
 
     # slot -> absolute row / byte offset helpers
@@ -106,30 +124,36 @@ def _setq(q: int) -> List[str]:
 def program_digits(lo: Layout) -> List[str]:
     """Phase 1.  c0 limb i at CT_IN[i], c1 limb i at CT_IN[Lr + i] (i = local index)."""
     out = [f"vsetvl {64 * lo.n:#x}"]
-    for i, d in enumerate(lo.owned_ct):
+    for i, d in enumerate(lo.owned_ct):                         # all inverse transforms
         out += _setq(lo.moduli[d])
-        out += [f"vle v0, abs+{lo.off(lo.ct_in + lo.Lr + i):#x}", "vintt v2, v0", "vaut v4, v2, 0x0",
-                f"vse v4, abs+{lo.off(lo.dig_slot(d)):#x}"]
-        out += [f"vle v0, abs+{lo.off(lo.ct_in + i):#x}", "vintt v2, v0", "vaut v0, v2, 0x0", "vntt v4, v0",
-                f"vse v4, abs+{lo.off(lo.rot + i):#x}"]
+        for c in range(2):
+            out += [f"vle v0, abs+{lo.off(lo.ct_in + c * lo.Lr + i):#x}", "vintt v2, v0",
+                    f"vse v2, abs+{lo.off(lo.s1 + c * lo.Lr + i):#x}"]
+    for i, d in enumerate(lo.owned_ct):                         # all automorphisms
+        out += _setq(lo.moduli[d])
+        out += [f"vle v0, abs+{lo.off(lo.s1 + lo.Lr + i):#x}", "vaut v2, v0, 0x0", f"vse v2, abs+{lo.off(lo.dig_slot(d)):#x}"]
+        out += [f"vle v0, abs+{lo.off(lo.s1 + i):#x}", "vaut v2, v0, 0x0", f"vse v2, abs+{lo.off(lo.s2 + i):#x}"]
+    for i, d in enumerate(lo.owned_ct):                         # rotated c0 back to NTT form
+        out += _setq(lo.moduli[d])
+        out += [f"vle v0, abs+{lo.off(lo.s2 + i):#x}", "vntt v2, v0", f"vse v2, abs+{lo.off(lo.rot + i):#x}"]
     return out + ["break"]
 
 
 def program_inner(lo: Layout, jl: int) -> List[str]:
-    """Phase 2 for the jl-th owned modulus: both accumulators stay in registers over the digits."""
+    """Phase 2 for the jl-th owned modulus."""
     j = lo.owned_all[jl]
     out = [f"vsetvl {64 * lo.n:#x}"] + _setq(lo.modulus(j))
-    for d in range(lo.L):
-        out += [f"vle v2, abs+{lo.off(lo.dig_slot(d)):#x}", "vfqmod v4, v2", "vntt v0, v4"]
-        for c in range(2):
-            acc = 6 + 2 * c                                     # v6, v8 (even bank)
-            out.append(f"vle v1, ksk+{((jl * lo.L + d) * 2 + c) * 8 * lo.n:#x}")
+    for d in range(lo.L):                                       # every digit under this modulus, NTT form
+        out += [f"vle v0, abs+{lo.off(lo.dig_slot(d)):#x}", "vntt v2, v0", f"vse v2, abs+{lo.off(lo.sd + d):#x}"]
+    for c in range(2):                                          # inner product with the key, per component
+        acc = 6 + 2 * c                                         # v6, v8 (even bank)
+        for d in range(lo.L):
+            out += [f"vle v0, abs+{lo.off(lo.sd + d):#x}", f"vle v1, ksk+{((jl * lo.L + d) * 2 + c) * 8 * lo.n:#x}"]
             if d == 0:
                 out.append(f"vfqmul.vv v{acc}, v0, v1")
             else:
                 out += ["vfqmul.vv v3, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v3"]
-    for c in range(2):
-        out.append(f"vse v{6 + 2 * c}, abs+{lo.off(lo.acc + 2 * jl + c):#x}")
+        out.append(f"vse v{acc}, abs+{lo.off(lo.acc + 2 * jl + c):#x}")
     return out + ["break"]
 
 
@@ -148,18 +172,34 @@ def program_finish(lo: Layout) -> List[str]:
     """Phase 4."""
     half = lo.special >> 1
     out = [f"vsetvl {64 * lo.n:#x}"]
-    for i, j in enumerate(lo.owned_ct):
+    own = list(enumerate(lo.owned_ct))
+    for i, j in own:                                            # t_c - floor(P/2) under q_j
+        out += _setq(lo.moduli[j])
+        for c in range(2):
+            out += [f"vle v0, abs+{lo.off(lo.t + c):#x}", f"vfqsub.vs v2, v0, {half:#x}",
+                    f"vse v2, abs+{lo.off(lo.s1 + c * lo.Lr + i):#x}"]
+    for i, j in own:                                            # ... to NTT form (in place)
+        out += _setq(lo.moduli[j])
+        for c in range(2):
+            s = lo.off(lo.s1 + c * lo.Lr + i)
+            out += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
+    for i, j in own:                                            # acc - that
+        out += _setq(lo.moduli[j])
+        jl = lo.owned_all.index(j)
+        for c in range(2):
+            out += [f"vle v0, abs+{lo.off(lo.acc + 2 * jl + c):#x}", f"vle v1, abs+{lo.off(lo.s1 + c * lo.Lr + i):#x}",
+                    "vfqsub.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.s2 + c * lo.Lr + i):#x}"]
+    for i, j in own:                                            # times P^-1; c1 is final
         q = lo.moduli[j]
         pinv = pow(lo.special % q, q - 2, q)
-        jl = lo.owned_all.index(j)
         out += _setq(q)
-        for c in range(2):
-            out += [f"vle v0, abs+{lo.off(lo.t + c):#x}", f"vfqsub.vs v2, v0, {half:#x}", "vntt v5, v2",
-                    f"vle v0, abs+{lo.off(lo.acc + 2 * jl + c):#x}", "vfqsub.vv v0, v0, v5",
-                    f"vfqmul.vs v0, v0, {pinv:#x}"]
-            if c == 0:
-                out += [f"vle v1, abs+{lo.off(lo.rot + i):#x}", "vfqadd.vv v0, v0, v1"]
-            out.append(f"vse v0, abs+{lo.off(lo.out + c * lo.Lr + i):#x}")
+        out += [f"vle v0, abs+{lo.off(lo.s2 + i):#x}", f"vfqmul.vs v2, v0, {pinv:#x}", f"vse v2, abs+{lo.off(lo.s1 + i):#x}"]
+        out += [f"vle v0, abs+{lo.off(lo.s2 + lo.Lr + i):#x}", f"vfqmul.vs v2, v0, {pinv:#x}",
+                f"vse v2, abs+{lo.off(lo.out + lo.Lr + i):#x}"]
+    for i, j in own:                                            # c0 += rotated c0
+        out += _setq(lo.moduli[j])
+        out += [f"vle v0, abs+{lo.off(lo.s1 + i):#x}", f"vle v1, abs+{lo.off(lo.rot + i):#x}", "vfqadd.vv v2, v0, v1",
+                f"vse v2, abs+{lo.off(lo.out + i):#x}"]
     return out + ["break"]
 
 
@@ -174,10 +214,6 @@ class Exchange:
         self.group = group
         self.tensor_of = tensor_of
         self.always = always          # run the collectives even for world == 1 (single-rank NCCL smoke test)
-
-    def _world(self):
-        import torch.distributed as dist
-        return dist.get_world_size(self.group)
 
     def all_gather_digits(self, vp, lo: Layout) -> None:
         if lo.world == 1 and not self.always:
@@ -233,9 +269,11 @@ def device_tensor(vp, row: int, nwords: int):
 
 
 class ShardedKeySwitch:
-    """Rotate + key-switch of one ciphertext whose limbs are sharded over ``world`` ranks."""
+    """Rotate + key-switch of one ciphertext whose limbs are sharded over ``world`` ranks.
 
-    PC = 0
+    The phase programs live side by side in the instruction ROM (4096 words,
+    ``vp_defines.vh:31``); when they do not fit (large L on few ranks) the per-modulus programs
+    of phase 2 are loaded one after the other at the same address."""
 
     def __init__(self, vp, n: int, moduli: Sequence[int], special: int, world: int = 1, rank: int = 0,
                  exchange: Optional[Exchange] = None, base_row: int = 0):
@@ -243,13 +281,27 @@ class ShardedKeySwitch:
         self.lo = Layout(n, list(moduli), special, world, rank, base_row)
         self.ex = exchange or Exchange()
         lo = self.lo
-        self._p_digits = isa.assemble("\n".join(program_digits(lo)))
-        self._p_inner = [isa.assemble("\n".join(program_inner(lo, jl))) for jl in range(lo.Mr)]
-        self._p_terms = isa.assemble("\n".join(program_moddown_terms(lo))) if lo.L in lo.owned_all else None
-        self._p_finish = isa.assemble("\n".join(program_finish(lo)))
-        for p in [self._p_digits, self._p_finish] + self._p_inner:
-            if len(p) > isa.IRAM_DEPTH:
-                raise ValueError("phase program exceeds the 4096-word instruction ROM")
+        asm = lambda lines: isa.assemble("\n".join(lines))
+        self._p_digits = asm(program_digits(lo))
+        self._p_inner = [asm(program_inner(lo, jl)) for jl in range(lo.Mr)]
+        self._p_terms = asm(program_moddown_terms(lo)) if lo.L in lo.owned_all else None
+        self._p_finish = asm(program_finish(lo))
+        progs = [self._p_digits, self._p_finish] + ([self._p_terms] if self._p_terms is not None else [])
+        fixed = sum(len(p) for p in progs)
+        inner = sum(len(p) for p in self._p_inner)
+        if max([len(p) for p in progs + self._p_inner]) > isa.IRAM_DEPTH:
+            raise ValueError("a phase program exceeds the 4096-word instruction ROM")
+        self._resident = fixed + inner <= isa.IRAM_DEPTH
+        self._pc = {}
+        if self._resident:                                      # everything loaded once
+            pc = 0
+            for name, p in [("digits", self._p_digits), ("finish", self._p_finish), ("terms", self._p_terms)] + \
+                           [(("inner", jl), p) for jl, p in enumerate(self._p_inner)]:
+                if p is None:
+                    continue
+                vp.load_isram(pc, p)
+                self._pc[name] = pc
+                pc += len(p)
 
     # -- data placement -------------------------------------------------------------------------
     def load_key(self, ksk_full: np.ndarray) -> None:
@@ -275,23 +327,27 @@ class ShardedKeySwitch:
         return self.vp.read(SPM, lo.row(lo.out), 2 * lo.Lr * lo.n).reshape(2, lo.Lr, lo.n)
 
     # -- the op -----------------------------------------------------------------------------------
-    def _run(self, words, step: int = 0) -> None:
-        self.vp.load_isram(self.PC, words)
-        rc = self.vp.run(self.PC, src0=0, src1=0, rslt=0, ksk=0, step=step)
+    def _run(self, name, words, step: int = 0) -> None:
+        if self._resident:
+            pc = self._pc[name]
+        else:
+            pc = 0
+            self.vp.load_isram(0, words)
+        rc = self.vp.run(pc, src0=0, src1=0, rslt=0, ksk=0, step=step)
         if rc:
-            raise RuntimeError(f"key-switch phase failed with status {rc}: {getattr(self.vp, 'last_error', '')}")
+            raise RuntimeError(f"key-switch phase {name} failed with status {rc}: {getattr(self.vp, 'last_error', '')}")
 
     def rotate(self, k: int) -> None:
         """Apply X -> X^k (k odd, reduced mod N by the engine like the reference) and switch
         the key, reading CT_IN and writing OUT."""
         lo = self.lo
         if lo.Lr:
-            self._run(self._p_digits, step=k)
+            self._run("digits", self._p_digits, step=k)
         self.ex.all_gather_digits(self.vp, lo)
-        for words in self._p_inner:
-            self._run(words)
+        for jl, words in enumerate(self._p_inner):
+            self._run(("inner", jl), words)
         if self._p_terms is not None:
-            self._run(self._p_terms)
+            self._run("terms", self._p_terms)
         self.ex.broadcast_terms(self.vp, lo)
         if lo.Lr:
-            self._run(self._p_finish)
+            self._run("finish", self._p_finish)
