@@ -261,6 +261,100 @@ __global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict_
   }
 }
 
+// ---- column pass for N = 2^12 .. 2^15 (n1 = 4 + E column stages, E = 0..3) -------------------------
+// A limb has R = 16 * 2^E rows of 256 columns.  A tile is R rows x C = 256 >> E columns (4096
+// words): thread (col = tid mod C, pl = tid div C) first holds rows pl + 2^E * k (k = 0..15) for
+// the radix-16 step over the stride-2^E .. stride-8*2^E stages (wave-uniform twiddles), then --
+// for E > 0 -- after one LDS exchange it holds 16 >> E groups of 2^E consecutive rows,
+//   row = ((kh * (16 >> E) + g) << E) + j,
+// for the last E stages.  Loads and stores are whole 2^(11-E)-byte row segments.  The reference's
+// own size, N = 8192, is E = 1.
+template <int E, bool INV, bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void ntt_col_small_kernel(const LimbJob *__restrict__ jobs,
+                                                            const PrimeDev *__restrict__ primes) {
+  constexpr int R = 16 << E, C = 256 >> E, GR = 16 >> E, PIT = R + 1;
+  __shared__ u64 sdata[E ? C * PIT : 1];
+  const int tid = threadIdx.x;
+  const uint32_t col = tid & (C - 1), hi = tid >> (8 - E);               // hi = pl (step A) = kh (step B)
+  const uint32_t limb = blockIdx.x >> E, cg = blockIdx.x & ((1u << E) - 1);
+  const LimbJob jb = jobs[limb];
+  const PrimeDev *pr = &primes[jb.prime];
+  const u64 q = pr->m.q, nq = pr->m.nq;
+  ctw_t blk = (ctw_t)(INV ? pr->tw.inv_blk : pr->tw.fwd_blk);            // block 0 = W[0..255]
+  cgptr_t src = (cgptr_t)jb.src + cg * C + col;
+  gptr_t dst = (gptr_t)jb.dst + cg * C + col;
+  auto rowA = [&](int k) -> uint32_t { return hi + ((uint32_t)k << E); };
+  auto rowB = [&](int i) -> uint32_t { return (((hi * GR) + ((uint32_t)i >> E)) << E) + ((uint32_t)i & ((1u << E) - 1)); };
+  // last E stages on the B-mapped registers: sub-stage t pairs i with i + (2^(E-1-t)) inside each
+  // group of 2^E; twiddle L = 2^(4+t) + ((kh*GR + g) << t) + sub-group
+  auto step_b = [&](u64 (&v)[16], auto bfly, bool fwd) {
+#pragma unroll
+    for (int tt = 0; tt < E; tt++) {
+      const int t = fwd ? tt : E - 1 - tt;
+      const int half = 1 << (E - 1 - t);
+#pragma unroll
+      for (int g = 0; g < GR; g++)
+#pragma unroll
+        for (int sg = 0; sg < (1 << t); sg++) {
+          const tw_t w = load_tw(blk + (16 << t) + (((hi * GR) + g) << t) + sg);
+#pragma unroll
+          for (int jj = 0; jj < half; jj++) {
+            const int i0 = (g << E) + sg * 2 * half + jj;
+            bfly(v[i0], v[i0 + half], w, tt);
+          }
+        }
+    }
+  };
+  u64 v[16];
+  if (!INV) {
+    constexpr int BIN = FIRST ? FWD_IN : FWD_MID;
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = ld_stream(&src[(size_t)rowA(k) << 8]);
+    fwd_radix16<true, BIN>(v, TwStepA{blk}, q, nq);
+    constexpr int B0 = bound_after4(BIN);
+    constexpr int BS[4] = {B0, next_bound(B0), next_bound(next_bound(B0)), next_bound(next_bound(next_bound(B0)))};
+    if (E) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) sdata[col * PIT + rowA(k)] = v[k];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; i++) v[i] = sdata[col * PIT + rowB(i)];
+      step_b(v, [&](u64 &X, u64 &Y, const tw_t &w, int tt) {
+        if (need_corr(BS[tt])) X = csub_borrow(X, q * (u64)corr_t(BS[tt]));
+        ct_bfly<false, false>(X, Y, w.w, w.wp, nq, q << 2);
+      }, true);
+    }
+    constexpr int BOUT = BS[E];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      u64 x = v[i];
+      if (LAST) x = canon_any(x, q, nq, (u32)pr->m.kc);
+      else if (BOUT > FWD_MID) x = csub_borrow(x, q * (u64)corr_t(BOUT));   // the row pass expects < FWD_MID*q
+      st_stream(&dst[(size_t)(E ? rowB(i) : rowA(i)) << 8], x);
+    }
+  } else {
+    const u64 fourq = q << 2;
+    if (E) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) v[i] = ld_stream(&src[(size_t)rowB(i) << 8]);
+      step_b(v, [&](u64 &X, u64 &Y, const tw_t &w, int) { gs_bfly<false>(X, Y, w.w, w.wp, nq, fourq); }, false);
+#pragma unroll
+      for (int i = 0; i < 16; i++) sdata[col * PIT + rowB(i)] = v[i];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = sdata[col * PIT + rowA(k)];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) v[k] = ld_stream(&src[(size_t)rowA(k) << 8]);
+    }
+    inv_radix16<true>(v, TwStepA{blk}, q, nq);
+    const u64 ni = pr->tw.n_inv, nip = pr->tw.n_inv_shoup;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+      st_stream(&dst[(size_t)rowA(k) << 8], LAST ? scale_canon(v[k], ni, nip, q, nq) : v[k]);
+  }
+}
+
 // ---- row pass: 16 lines of 256 contiguous points per workgroup, 4 lines per WAVE ------------------
 // The four waves of a workgroup are independent: each owns 4 lines and a private LDS region,
 // so the pass has no s_barrier at all (wave_lds_fence).  Lines of a tile are the same row of
@@ -438,6 +532,22 @@ static void launch_cols(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d
 }
 
 template <bool INV, bool FIRST, bool LAST>
+static void launch_cols_small(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
+                              unsigned e, uint64_t *launches) {
+  if (!count) return;
+  switch (e) {
+#define ALOHA_COL_SMALL(EE)                                                                                  \
+  case EE:                                                                                                   \
+    hipLaunchKernelGGL((ntt_col_small_kernel<EE, INV, FIRST, LAST>), dim3(count << EE), dim3(256), 0, st, d_jobs, \
+                       d_primes);                                                                            \
+    break;
+    ALOHA_COL_SMALL(0) ALOHA_COL_SMALL(1) ALOHA_COL_SMALL(2) ALOHA_COL_SMALL(3)
+#undef ALOHA_COL_SMALL
+  }
+  if (launches) ++*launches;
+}
+
+template <bool INV, bool FIRST, bool LAST>
 static void launch_rows(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes,
                         const TileDesc *d_tiles, uint32_t ntiles, bool uniform, uint64_t *launches) {
   if (!ntiles) return;
@@ -474,9 +584,11 @@ hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *
   if (logn < 10 || logn > 16) return hipErrorInvalidValue;
   const unsigned n1 = logn - 8;
   const bool col_tiles = (n1 == 8);
+  const bool col_small = (n1 >= 4 && n1 <= 7);
   if (!inverse) {
-    if (col_tiles) {
-      launch_cols<false, true, false>(st, d_jobs + begin, d_primes, count, launches);
+    if (col_tiles || col_small) {
+      if (col_tiles) launch_cols<false, true, false>(st, d_jobs + begin, d_primes, count, launches);
+      else launch_cols_small<false, true, false>(st, d_jobs + begin, d_primes, count, n1 - 4, launches);
       launch_rows<false, false, true>(st, inplace, d_primes, d_lds_tiles, n_lds, true, launches);
       launch_rows<false, false, true>(st, inplace, d_primes, d_glb_tiles, n_glb, false, launches);
     } else {
@@ -491,6 +603,8 @@ hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *
     launch_rows<true, true, false>(st, d_jobs, d_primes, d_glb_tiles, n_glb, false, launches);
     if (col_tiles) {
       launch_cols<true, false, true>(st, inplace + begin, d_primes, count, launches);
+    } else if (col_small) {
+      launch_cols_small<true, false, true>(st, inplace + begin, d_primes, count, n1 - 4, launches);
     } else {
       hipError_t e = ntt_radix2_batch(st, inplace + begin, d_primes, count, logn, 8, logn, true, true, true, launches);
       if (e != hipSuccess) return e;

@@ -94,6 +94,24 @@ def poly_mul(n: int, moduli: Sequence[int]) -> str:
     return "\n".join(out + ["break"])
 
 
+def poly_mul_batched(n: int, moduli: Sequence[int], scratch_row: int) -> str:
+    """Same product as ``poly_mul`` written loop by loop (all NTT(a), all NTT(b), all pointwise
+    products, all inverse transforms) so a fusing sequencer runs each loop as one batched launch.
+    NTT(b) goes to ``len(moduli)`` scratch limbs at absolute row ``scratch_row``."""
+    out = [f"vsetvl {64 * n:#x}"]
+    lb = _lb(n)
+    for j, q in enumerate(moduli):
+        out += _setq(q) + [f"vle v0, src0+{j * lb:#x}", "vntt v2, v0", f"vse v2, rslt+{j * lb:#x}"]
+    for j, q in enumerate(moduli):
+        out += _setq(q) + [f"vle v0, src1+{j * lb:#x}", "vntt v2, v0", f"vse v2, abs+{scratch_row * 1024 + j * lb:#x}"]
+    for j, q in enumerate(moduli):
+        out += _setq(q) + [f"vle v0, rslt+{j * lb:#x}", f"vle v1, abs+{scratch_row * 1024 + j * lb:#x}",
+                           "vfqmul.vv v2, v0, v1", f"vse v2, rslt+{j * lb:#x}"]
+    for j, q in enumerate(moduli):
+        out += _setq(q) + [f"vle v0, rslt+{j * lb:#x}", "vintt v2, v0", f"vse v2, rslt+{j * lb:#x}"]
+    return "\n".join(out + ["break"])
+
+
 def keyswitch(n: int, moduli: Sequence[int], special: int) -> str:
     """Rotate (automorphism k = csr_step) + hybrid key-switch, one digit per prime, one
     special prime, rounding mod-down: the algorithm of keyswitch.mem:1-122 for

@@ -364,15 +364,19 @@ def test_poly_mul_program_config3(engine):
     rng = np.random.default_rng(33)
     a = np.stack([residues(rng, n, q) for q in mods]); b = np.stack([residues(rng, n, q) for q in mods])
     words = programs.assemble(programs.poly_mul(n, mods))
-    o = oracle.OracleVP(spm_rows=3 * L * rows, ksk_rows=1)
+    words_b = programs.assemble(programs.poly_mul_batched(n, mods, scratch_row=3 * L * rows))
+    o = oracle.OracleVP(spm_rows=4 * L * rows, ksk_rows=1)
     res = []
-    for vp in (engine, o):
+    for vp, w in ((engine, words), (o, words), (engine, words_b), (o, words_b)):
         vp.write(SPM, 0, a.reshape(-1)); vp.write(SPM, L * rows, b.reshape(-1))
-        vp.load_isram(512, words)
+        vp.load_isram(512, np.zeros((512, 3), np.uint32)); vp.load_isram(512, w)
+        k0 = vp.stats()["kernel_launches"] if hasattr(vp, "stats") else 0
         assert vp.run(512, src0=0, src1=L * rows, rslt=2 * L * rows) == 0
         vp.sync()
         res.append(vp.read(SPM, 2 * L * rows, L * n))
-    assert np.array_equal(res[0], res[1])
+        if w is words_b and hasattr(vp, "stats"):
+            assert vp.stats()["kernel_launches"] - k0 <= 8        # 3 transform batches (2 kernels each) + 1 product batch
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[2], res[3]) and np.array_equal(res[0], res[2])
     # and the answer is the negacyclic product: check one coefficient by direct convolution
     q = mods[0]
     j = 12345

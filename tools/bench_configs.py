@@ -61,9 +61,9 @@ def config3():
     rng = np.random.default_rng(3)
     a = np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in mods])
     b = np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in mods])
-    with avp.VP(spm_rows=3 * L * rows, ksk_rows=1, max_log_n=14) as vp:
+    with avp.VP(spm_rows=4 * L * rows, ksk_rows=1, max_log_n=14) as vp:
         vp.write(SPM, 0, a.reshape(-1)); vp.write(SPM, L * rows, b.reshape(-1))
-        vp.load_isram(0, programs.assemble(programs.poly_mul(n, mods)))
+        vp.load_isram(0, programs.assemble(programs.poly_mul_batched(n, mods, scratch_row=3 * L * rows)))
         run = lambda: vp.run(0, src0=0, src1=L * rows, rslt=2 * L * rows)
         assert run() == 0
         got = vp.read(SPM, 2 * L * rows, n)
