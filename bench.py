@@ -85,11 +85,19 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the engine has no CPU path", file=sys.stderr)
         return 2
+    # Rehearsal knobs (not used by the driver): ALOHA_BENCH_BACKEND=gloo and ALOHA_BENCH_DEVICE=0
+    # let several ranks share one GPU to exercise the multi-rank control flow on a 1-GPU box.
+    backend = os.environ.get("ALOHA_BENCH_BACKEND", "nccl")
+    if "ALOHA_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["ALOHA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     from aloha_amd import vp as avp
 
@@ -141,7 +149,7 @@ def main() -> int:
     dev_ms = ev0.elapsed_time(ev1)                          # device time of the K steps on the engine's stream
     launches = vp.stats()["kernel_launches"] - launches0
     if dist is not None:
-        t = torch.tensor([elapsed, dev_ms], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, dev_ms], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
 
