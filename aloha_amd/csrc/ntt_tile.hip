@@ -11,27 +11,33 @@
 //   forward : COLUMN pass = the first n1 stages (stride >= 256: fixed x, over r)
 //             ROW    pass = the last 8 stages  (inside one 2 KiB row)
 //   inverse : ROW pass first (strides 1..128), then the COLUMN pass.
-// One workgroup (256 threads, 4 waves) owns a tile of 16 "lines" x 256 points = 32 KiB:
-//   column tile (n1 = 8 only): 16 adjacent columns of one limb (128-byte segments per row)
-//   row tile: 16 lines = (16 >> pb) rows x 2^pb limbs that share a prime (pb = 4..0), so one
-//             4 KiB twiddle block feeds the same row of 2^pb limbs.
+// A tile is 16 "lines" x 256 points = 32 KiB:
+//   column tile, N = 2^16 (ntt_col_kernel): 16 adjacent columns of one limb, one 256-thread
+//             workgroup, one LDS exchange + barrier, XCD-affine tile order;
+//   column tile, N = 2^12..2^15 (ntt_col_small_kernel<E>): 16*2^E rows x 256>>E columns;
+//   row tile (ntt_row_kernel): 16 lines = (16 >> pb) rows x 2^pb limbs that share a prime
+//             (pb = 4..0), so one 4 KiB twiddle block feeds the same row of 2^pb limbs; each
+//             WAVE owns 4 lines and runs as its own 64-thread workgroup, no barrier.
 // A 256-point line transform is two radix-16 steps (4 butterfly stages each, 16 values per
-// thread in registers) with a transpose through LDS in between, and one more so that global
-// stores leave in the same 128-byte-segment pattern as the loads.
-// Column passes for n1 < 8 (N < 2^16) run as radix-2 stage launches (ntt_radix2_stages).
+// thread in registers) with a transpose through LDS in between; the row pass transposes back
+// so that global stores leave in the same 128-byte-segment pattern as the loads (measured
+// free).  N < 2^12 falls back to radix-2 stage launches (ntt_radix2_batch).
 //
 // Twiddles: for both passes stage s' (0..7) of a 256-point line uses entry
 //   L = 2^s' + (p >> (8 - s'))      p = point index inside the line
 // of a 256-entry block of (w, floor(w*2^64/q)) pairs: block 0 is W[0..255] (column pass),
 // block 1+r is the row-r slice W[2^(n1+s') + r*2^s' + i] re-indexed the same way (built by
-// the host, vp_engine.cpp).  Tiles with <= 4 twiddle blocks stage them in LDS (the first
-// radix-16 step then reads them at wave-uniform addresses = LDS broadcast); tiles with more
-// (bundles of 1-2 limbs) read them through the vector cache.
+// the host, vp_engine.cpp).  The first radix-16 step's 15 entries do not depend on the
+// thread: scalar loads into SGPR operands.  The second step's entries depend on the thread's
+// high nibble: vector loads through the cache (16 distinct 16-byte words per instruction).
 //
-// Arithmetic: lazy, see modarith.hpp.  Forward: relaxed CT butterflies, values < 16q, one
-// borrow-subtract per element between radix-16 steps.  Inverse: Harvey GS butterflies, values
-// < 2q, N^-1 fused into the last pass.  HBM traffic per pass: read + write of the limb
-// (+ twiddle blocks); algorithmic bytes per transform: 16*N.
+// Arithmetic: lazy, see modarith.hpp.  Forward: relaxed CT butterflies with approximate Shoup
+// quotients, values < 16q, borrow-subtracts placed by a compile-time range plan.  Inverse:
+// Harvey GS butterflies, values < 4q, N^-1 fused into the last pass.  HBM traffic per pass:
+// read + write of the limb (+ twiddle blocks); algorithmic bytes per transform: 16*N
+// (SURVEY 8d).  Timing experiments (ALOHA_ABLATE builds, profiles/): memory skeleton ~195 us
+// per pass per 1024 limbs, arithmetic ~150-180 us; in the row pass the transpose-back costs
+// nothing, the final canonicalisation ~4 %, the per-lane second-step twiddles ~7 %.
 #include <vector>
 
 #include "kernels.hpp"
@@ -413,11 +419,17 @@ __global__ __launch_bounds__(64) void ntt_row_kernel(const LimbJob *__restrict__
     wave_lds_fence();
 #pragma unroll
     for (int jj = 0; jj < 16; jj++) v[jj] = lds[ldsB + jj];
+#if ALOHA_ABLATE == 3   // timing experiment: second-step twiddles from the wave-uniform block entries
+    fwd_radix16<false, bound_after4(BIN)>(v, TwStepA{blkA}, q, nq);
+#else
     fwd_radix16<false, bound_after4(BIN)>(v, TwStepB{blkB, (int)khB}, q, nq);
+#endif
+#if ALOHA_ABLATE != 5   // timing experiment 5: no final canonicalisation
     if (LAST) {
 #pragma unroll
       for (int jj = 0; jj < 16; jj++) v[jj] = canon_any(v[jj], q, nq, (u32)pr->m.kc);
     }
+#endif
   } else {
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) lds[ldsA + 17 * kk] = v[kk];
@@ -427,12 +439,14 @@ __global__ __launch_bounds__(64) void ntt_row_kernel(const LimbJob *__restrict__
     inv_radix16<false>(v, TwStepB{blkB, (int)khB}, q, nq);               // < 4q throughout
   }
   // back to the A mapping: second inverse step / 128-byte-segment stores
+#if ALOHA_ABLATE != 4   // timing experiment 4: skip the transpose back (stores land in the wrong order)
   wave_lds_fence();
 #pragma unroll
   for (int jj = 0; jj < 16; jj++) lds[ldsB + jj] = v[jj];
   wave_lds_fence();
 #pragma unroll
   for (int kk = 0; kk < 16; kk++) v[kk] = lds[ldsA + 17 * kk];
+#endif
   if (INV) {
     inv_radix16<UNIA>(v, TwStepA{blkA}, q, nq);
     if (LAST) {
