@@ -322,6 +322,102 @@ def test_sequencer_fusion_is_exact_and_batches(engine):
         plain.close()
 
 
+def _random_program(rng, n, primes, nslots, length):
+    """Random straight-line program over v0..v9 and `nslots` limb slots of src0.  Registers that
+    a transform left undefined (its vs1) or that were never written are not read."""
+    lines = [f"vsetvl {64 * n:#x}", f"vsetq {primes[0]:#x}"]
+    defined = set()
+    regs = list(range(10))
+
+    def pick_def(parity=None):
+        c = [r for r in sorted(defined) if parity is None or r % 2 == parity]
+        return int(rng.choice(c)) if c else None
+
+    def slot():
+        return f"src0+{int(rng.integers(nslots)) * 8 * n:#x}"
+
+    for _ in range(length):
+        op = rng.choice(["vle", "vle", "vse", "vv", "vs", "un", "perm", "ntt", "setq", "dot"])
+        vd = int(rng.choice(regs))
+        if op == "vle":
+            lines.append(f"vle v{vd}, {slot()}"); defined.add(vd)
+        elif op == "vse":
+            r = pick_def()
+            if r is not None:
+                lines.append(f"vse v{r}, {slot()}")
+        elif op == "vv":
+            a = pick_def()
+            b = pick_def(1 - a % 2) if a is not None else None
+            if b is not None:
+                lines.append(f"{rng.choice(['vfqmul', 'vfqadd', 'vfqsub'])}.vv v{vd}, v{a}, v{b}"); defined.add(vd)
+        elif op == "vs":
+            a = pick_def()
+            if a is not None:
+                s = int(rng.integers(1, 1 << 59))
+                m = rng.choice(["vfqmul.vs", "vfqadd.vs", "vfqsub.vs", "vfqsub.sv"])
+                lines.append(f"{m} v{vd}, {s:#x}, v{a}" if m.endswith(".sv") else f"{m} v{vd}, v{a}, {s:#x}")
+                defined.add(vd)
+        elif op == "un":
+            a = pick_def()
+            if a is not None:
+                lines.append(f"{rng.choice(['vfqmod', 'vcp'])} v{vd}, v{a}"); defined.add(vd)
+        elif op == "perm":
+            a = pick_def()
+            if a is not None:
+                # (the raw `q - x` of vaut needs a canonical x: real programs permute iNTT outputs)
+                t2 = int(rng.choice(regs))
+                lines.append(f"vcp v{t2}, v{a}")
+                lines.append(f"{rng.choice(['vaut', 'vroli'])} v{vd}, v{t2}, {2 * int(rng.integers(8)):#x}")
+                defined.update({t2, vd})
+        elif op == "ntt":
+            a = pick_def()
+            if a is not None and a != vd:
+                lines.append(f"{rng.choice(['vntt', 'vintt'])} v{vd}, v{a}")
+                defined.discard(a); defined.add(vd)
+        elif op == "setq":
+            lines.append(f"vsetq {int(rng.choice(primes)):#x}")
+        elif op == "dot":                                    # the accumulate idiom of the key-switch inner product
+            acc, t = 6, 3
+            for i in range(int(rng.integers(1, 4))):
+                lines += [f"vle v0, {slot()}", f"vle v1, {slot()}"]
+                lines += [f"vfqmul.vv v{acc}, v0, v1"] if i == 0 else [f"vfqmul.vv v{t}, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v{t}"]
+            defined.update({0, 1, acc}); defined.add(t) if i else None
+            if rng.integers(2):
+                lines.append(f"vse v{acc}, {slot()}")
+    for r in sorted(defined):                                # flush every live register to memory
+        lines.append(f"vse v{r}, src0+{(nslots + r) * 8 * n:#x}")
+    return "\n".join(lines + ["break"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_programs_fused_unfused_oracle(engine, seed):
+    """Differential fuzz of the sequencer: fused engine == unfused engine == oracle on all memory."""
+    rng = np.random.default_rng(1000 + seed)
+    logn = int(rng.choice([10, 12, 13]))
+    n, rows, nslots = 1 << logn, (1 << logn) // 128, 6
+    primes = [oracle.nth_prime(13, i) for i in range(2)]          # q = 1 mod 2^14 serves every N <= 8192
+    mem = np.stack([residues(rng, n, primes[0]) for _ in range(nslots)])
+    mem[1, :8] = 0                                                # zeros exercise the flipped-zero corner of vaut
+    words = isa.assemble(_random_program(rng, n, primes, nslots, 40))
+    total = (nslots + 10) * n
+    plain = avp.VP(spm_rows=(nslots + 10) * rows, ksk_rows=1, max_log_n=13, flags=avp.FLAG_NO_FUSION)
+    o = oracle.OracleVP(spm_rows=(nslots + 10) * rows, ksk_rows=1)
+    try:
+        res = []
+        for vp in (engine, plain, o):
+            vp.write(SPM, 0, np.zeros(total, np.uint64))
+            vp.write(SPM, 0, mem.reshape(-1))
+            vp.load_isram(0, np.zeros((1024, 3), np.uint32)); vp.load_isram(0, words)
+            rc = vp.run(0, src0=0, step=2 * seed + 1)
+            vp.sync()
+            res.append((rc, vp.read(SPM, 0, total)))
+        assert res[0][0] == res[1][0] == res[2][0] == 0
+        assert np.array_equal(res[0][1], res[2][1]), "fused engine vs oracle"
+        assert np.array_equal(res[1][1], res[2][1]), "unfused engine vs oracle"
+    finally:
+        plain.close()
+
+
 def test_case0_chain_fused_equals_unfused():
     plain = avp.VP(spm_rows=1 << 16, ksk_rows=1 << 16, max_log_n=13, flags=avp.FLAG_NO_FUSION)
     try:
