@@ -62,7 +62,8 @@ struct alignas(16) tw_t { u64 w, wp; };
 #define ALOHA_AS_CONST __attribute__((address_space(4)))
 typedef const ALOHA_AS_GLOBAL u64 *cgptr_t;
 typedef ALOHA_AS_GLOBAL u64 *gptr_t;
-typedef const ALOHA_AS_CONST tw_t *ctw_t;
+typedef const ALOHA_AS_CONST tw_t *ctw_t;    // invariant loads: scalar when uniform, free to sink next to their use
+typedef const ALOHA_AS_GLOBAL tw_t *gtw_t;   // ordinary global loads: keep their program order
 
 // Limb data is touched exactly once per pass: ALOHA_NT=1 marks those accesses non-temporal.
 #ifndef ALOHA_NT
@@ -175,6 +176,22 @@ struct TwStepB {                   // stages s' = 4..7: L = 2^(4+ss) + kh*2^ss +
   }
 };
 
+struct TwStepReg {                 // stages 4..7 from 15 preloaded registers: index 2^ss - 1 + g
+  const tw_t (&r)[15];
+  __device__ __forceinline__ tw_t operator()(int ss, int g) const { return r[(1 << ss) - 1 + g]; }
+};
+
+template <int NPRE>
+struct TwStepMixT {                // the first NPRE entries preloaded, the rest read at use
+  const tw_t (&r)[15];
+  ctw_t blk;
+  int kh;
+  __device__ __forceinline__ tw_t operator()(int ss, int g) const {
+    const int idx = (1 << ss) - 1 + g;
+    return idx < NPRE ? r[idx] : load_tw(blk + (16 << ss) + (kh << ss) + g);
+  }
+};
+
 // in-wave LDS hand-off: LDS instructions of one wave execute in issue order, so lanes of the
 // same wave need no s_barrier between a ds_write and a dependent ds_read -- only the compiler
 // must keep the order.
@@ -236,13 +253,24 @@ __global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict_
 #else
     for (int kk = 0; kk < 16; kk++) v[kk] = ld_stream(&(src + ((size_t)(16 * kk) << 8))[offA]);
 #endif
+    // second-step twiddles: issued now (ordinary global loads keep their program order), so
+    // their L2 latency hides under the first radix-16 step instead of stalling the second
+    tw_t twb[15];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++)
+#pragma unroll
+      for (int g = 0; g < (1 << ss); g++) {
+        const gtw_t p = (gtw_t)blk + (16 << ss) + (slow << ss) + g;
+        twb[(1 << ss) - 1 + g].w = p->w;
+        twb[(1 << ss) - 1 + g].wp = p->wp;
+      }
     fwd_radix16<true, BIN>(v, TwStepA{blk}, q, nq);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) sdata[col * PITCH + slow + 16 * kk] = v[kk];
     __syncthreads();
 #pragma unroll
     for (int jj = 0; jj < 16; jj++) v[jj] = sdata[col * PITCH + 16 * slow + jj];
-    fwd_radix16<false, bound_after4(BIN)>(v, TwStepB{blk, (int)slow}, q, nq);
+    fwd_radix16<false, bound_after4(BIN)>(v, TwStepReg{twb}, q, nq);
 #pragma unroll
     for (int jj = 0; jj < 16; jj++) {
 #if ALOHA_ABLATE == 2
@@ -413,6 +441,19 @@ __global__ __launch_bounds__(64) void ntt_row_kernel(const LimbJob *__restrict__
 #endif
   if (!INV) {
     constexpr int BIN = FIRST ? FWD_IN : FWD_MID;
+#ifndef ALOHA_ROW_PRELOAD
+#define ALOHA_ROW_PRELOAD 7   // second-step twiddles issued before the first step: 0, 7 (sub-stages 0..2) or 15 (all)
+#endif
+    tw_t twb[15];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++)
+#pragma unroll
+      for (int g = 0; g < (1 << ss); g++)
+        if ((1 << ss) - 1 + g < ALOHA_ROW_PRELOAD) {
+          const gtw_t p = (gtw_t)blkB + (16 << ss) + (khB << ss) + g;
+          twb[(1 << ss) - 1 + g].w = p->w;
+          twb[(1 << ss) - 1 + g].wp = p->wp;
+        }
     fwd_radix16<UNIA, BIN>(v, TwStepA{blkA}, q, nq);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) lds[ldsA + 17 * kk] = v[kk];
@@ -422,7 +463,7 @@ __global__ __launch_bounds__(64) void ntt_row_kernel(const LimbJob *__restrict__
 #if ALOHA_ABLATE == 3   // timing experiment: second-step twiddles from the wave-uniform block entries
     fwd_radix16<false, bound_after4(BIN)>(v, TwStepA{blkA}, q, nq);
 #else
-    fwd_radix16<false, bound_after4(BIN)>(v, TwStepB{blkB, (int)khB}, q, nq);
+    fwd_radix16<false, bound_after4(BIN)>(v, TwStepMixT<ALOHA_ROW_PRELOAD>{twb, blkB, (int)khB}, q, nq);
 #endif
 #if ALOHA_ABLATE != 5   // timing experiment 5: no final canonicalisation
     if (LAST) {

@@ -75,6 +75,7 @@ def main() -> int:
     ap.add_argument("--primes", type=int, default=32)
     ap.add_argument("--polys", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inverse", action="store_true", help="time vintt instead (side metric; headline is forward)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,8 +125,9 @@ def main() -> int:
         if not np.array_equal(got, oracle.ntt(first_in, primes[0])):
             print("bench.py: GPU result differs from the oracle", file=sys.stderr)
             return 3
+    inv = bool(args.inverse)
     for _ in range(max(0, args.warmup - 1)):
-        vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli)
+        vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli, inverse=inv)
     vp.sync()
     launches0 = vp.stats()["kernel_launches"]
 
@@ -140,7 +142,7 @@ def main() -> int:
     with torch.cuda.stream(stream):
         ev0.record(stream)
         for _ in range(args.steps):
-            vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli)
+            vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli, inverse=inv)
         ev1.record(stream)
     vp.sync()
     torch.cuda.synchronize()
@@ -159,7 +161,7 @@ def main() -> int:
         dev_s_step = dev_ms / 1e3 / args.steps
         achieved = alg_bytes_step / dev_s_step / 1e9
         out = {
-            "metric": "fwd-NTT/s at N=2^16, 60-bit prime", "value": total_ntts / elapsed, "unit": "NTT/s",
+            "metric": ("inv-NTT/s" if inv else "fwd-NTT/s") + " at N=2^16, 60-bit prime", "value": total_ntts / elapsed, "unit": "NTT/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",

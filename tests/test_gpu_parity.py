@@ -452,6 +452,70 @@ def test_error_codes_match_oracle(engine):
     assert engine.run(2048) == avp.ERR_DECODE
 
 
+def test_boundary_and_edge_cases(engine):
+    """Empty batches, exact-fit and one-past-the-end row ranges, ROM bounds, pointer-select
+    corners of vle/vse (vp_top_full.sv:105-117) -- engine and oracle agree everywhere."""
+    n, rows = 8192, 64
+    q = Q0
+    rng = np.random.default_rng(9)
+    a = residues(rng, n, q)
+    # empty batch is a no-op; a batch ending exactly at the last row is fine; one row further is not
+    engine.ntt_rows(SPM, 0, 0, 13, [])
+    last = engine.spm_rows - rows
+    engine.write(SPM, last, a)
+    engine.ntt_rows(SPM, last, last, 13, [q])
+    assert np.array_equal(engine.read(SPM, last, n), oracle.ntt(a, q))
+    with pytest.raises(avp.AlohaError) as e:
+        engine.ntt_rows(SPM, last + 1, last + 1, 13, [q])
+    assert e.value.status == avp.ERR_ADDR
+    with pytest.raises(avp.AlohaError) as e:
+        engine.write(SPM, engine.spm_rows - 1, np.zeros(129, np.uint64))
+    assert e.value.status == avp.ERR_ADDR
+    with pytest.raises(avp.AlohaError) as e:
+        engine.read(KSK, engine.ksk_rows, 1)
+    assert e.value.status == avp.ERR_ADDR
+    with pytest.raises(avp.AlohaError) as e:
+        engine.ntt_rows(SPM, 0, 0, 13, [q + 2])
+    assert e.value.status == avp.ERR_MODULUS
+    with pytest.raises(avp.AlohaError) as e:
+        engine.ntt_rows(SPM, 0, 0, 9, [q])
+    assert e.value.status == avp.ERR_VL
+    # instruction ROM bounds
+    with pytest.raises(avp.AlohaError) as e:
+        engine.load_isram(4095, np.zeros((2, 3), np.uint32))
+    assert e.value.status == avp.ERR_ADDR
+    engine.load_isram(4095, isa.assemble("break"))
+    assert engine.run(4095) == 0
+    engine.load_isram(4095, isa.assemble("nop"))
+    o = oracle.OracleVP()
+    o.load_isram(4095, isa.assemble("nop"))
+    assert engine.run(4095) == o.run(4095) == avp.ERR_NOBREAK
+    # pointer selects: 1 = src1, 2 = rslt, 15 = KSK for loads but SPM base 0 for stores, others base 0
+    prog = f"""
+        vsetvl {64 * n:#x}
+        vsetq {q:#x}
+        vle v0, ksk+0x0
+        vle v1, src1+0x0
+        vfqadd.vv v2, v0, v1
+        vse v2, ksk+{8 * n:#x}
+        vle v3, abs+{8 * n:#x}
+        vfqmul.vv v4, v0, v3
+        vse v4, rslt+0x0
+        break
+    """
+    kdat, sdat = residues(rng, n, q), residues(rng, n, q)
+    outs = []
+    for vp in (engine, o):
+        vp.write(KSK, 5 * rows, kdat); vp.write(SPM, 7 * rows, sdat)
+        vp.write(SPM, 0, np.zeros(4 * n, np.uint64))
+        vp.load_isram(0, np.zeros((16, 3), np.uint32)); vp.load_isram(0, isa.assemble(prog))
+        assert vp.run(0, src0=0, src1=7 * rows, rslt=2 * rows, ksk=5 * rows) == 0
+        vp.sync()
+        outs.append(vp.read(SPM, 0, 4 * n))
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0][n:2 * n], (kdat + sdat) % np.uint64(q))       # the `vse ..., ksk+` landed in SPM row `rows`
+
+
 def test_poly_mul_program_config3(engine):
     """BASELINE config 3: c = iNTT(NTT(a) . NTT(b)), N = 2^14, 8 limbs, via the ISA."""
     logn, n, L = 14, 1 << 14, 8
