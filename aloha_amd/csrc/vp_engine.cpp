@@ -864,6 +864,8 @@ aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64
   const uint64_t bytes = (uint64_t)count * rows_per_limb * ALOHA_ROW_BYTES;
   u64 *src = space_ptr(vp, space, src_row, bytes), *dst = space_ptr(vp, space, dst_row, bytes);
   if (!src || !dst) return fail(vp, ALOHA_ERR_ADDR, "ntt_rows: %u limbs at rows %llu/%llu outside space %d", count, (u64)src_row, (u64)dst_row, space);
+  if (src != dst && src < dst + bytes / 8 && dst < src + bytes / 8)      // limbs are transformed concurrently
+    return fail(vp, ALOHA_ERR_ARG, "ntt_rows: source and destination ranges overlap without being equal");
   // steady state: identical arguments => reuse the resolved job list (no prime checks, no allocation)
   for (const RowsKey &k : vp->rows_cache)
     if (k.space == space && k.dst_row == dst_row && k.src_row == src_row && k.log_n == log_n && k.count == count &&

@@ -102,7 +102,8 @@ aloha_status aloha_vp_sync(aloha_vp *vp);   /* `done` */
 
 /* ---- batched transforms on rows (the fused form of N x {vsetq; vle; vntt|vintt; vse}) ---------
  * count limbs of 2^log_n coefficients; limb i is read at src_row + i*(N/128) and written at
- * dst_row + i*(N/128) (src_row == dst_row allowed), under modulus moduli[i].  Identical
+ * dst_row + i*(N/128) (src_row == dst_row allowed; ranges that overlap otherwise are rejected
+ * with ALOHA_ERR_ARG: the limbs are transformed concurrently), under modulus moduli[i].  Identical
  * results to running the encode_post-style program (encode_post.mem:1-12) limb by limb. */
 aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64_t src_row,
                                uint32_t log_n, const uint64_t *moduli, uint32_t count, int inverse);

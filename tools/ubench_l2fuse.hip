@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void k_fused(u64 *data, Ctl *ctl, u32 *coldone
       }
       // the real kernel transposes through LDS; here the exchange is emulated by each thread writing the
       // rows of the B mapping with values recomputed from the index (same store pattern, same bytes)
+      __syncthreads();
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const u64 idx = ((u64)g << 16) + ((16 * slow + j) << 8) + tile * 16 + col;
@@ -148,6 +149,98 @@ __global__ __launch_bounds__(256) void k_fused(u64 *data, Ctl *ctl, u32 *coldone
   if (wrong) atomicAdd(&ctl->stats[10], wrong);
 }
 
+
+// ---- second scheduler: TEAMS.  The workgroups of an XCD number themselves (one atomic each) and
+// form teams of 16; a team takes limbs one at a time: member m does column tile m, the team meets
+// at a counter, member m does row tile m.  Per limb and workgroup: one mailbox poll, one arrival
+// add, one arrival poll.  L2 footprint = one limb per team.
+struct TeamCtl {
+  u32 xcd_count[8][32];
+  u32 next_limb[32];
+  u32 timeout[32];
+  u32 stats[32];             // [0..7] workgroups per XCD, [8] spins, [10] wrong words (row loads), [11] wrong words (col loads)
+  // followed by: mail[8][8][iters], arrive[8][8][iters]
+};
+
+template <int LD>
+__global__ __launch_bounds__(256) void k_team(u64 *data, TeamCtl *ctl, u32 *mail_, u32 *arrive_, u32 nlimbs, u32 teams, u32 iters, u32 pass) {
+  __shared__ u32 sh[2];
+  const u32 tid = threadIdx.x;
+  const u32 xcc = xcc_id();
+  if (tid == 0) {
+    sh[0] = __hip_atomic_fetch_add((gu32)&ctl->xcd_count[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAdd(&ctl->stats[xcc], 1u);
+  }
+  __syncthreads();
+  const u32 lidx = sh[0], team = lidx >> 4, member = lidx & 15;
+  __syncthreads();
+  if (team >= teams) return;
+  gu32 mail = (gu32)mail_ + (size_t)(xcc * 8 + team) * iters;
+  gu32 arrive = (gu32)arrive_ + (size_t)(xcc * 8 + team) * iters;
+  u32 wrong_row = 0, wrong_col = 0, spins_total = 0;
+  for (u32 k = 0; k < iters; k++) {
+    if (tid == 0) {
+      u32 g;
+      if (member == 0) {
+        g = __hip_atomic_fetch_add((gu32)&ctl->next_limb[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mail + k, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        u32 spins = 0, m;
+        while ((m = ld_sc1(mail + k)) == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 17) || ((spins & 255) == 0 && ld_sc1((gu32)&ctl->timeout[0]))) { atomicAdd(&ctl->timeout[0], 1u); m = 0xffffffffu; break; }
+        }
+        spins_total += spins;
+        g = m - 1;
+      }
+      sh[0] = g;
+    }
+    __syncthreads();
+    const u32 g = sh[0];
+    if (g >= nlimbs) break;
+    gptr base = (gptr)data + ((size_t)g << 16);
+    u64 v[16];
+    {
+      const u32 col = tid & 15, slow = tid >> 4, tile = member;
+      gptr p = base + tile * 16 + col;
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) v[kk] = __builtin_nontemporal_load(p + ((size_t)(slow + 16 * kk) << 8));
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) wrong_col += v[kk] != expect0(((u64)g << 16) + ((slow + 16 * kk) << 8) + tile * 16 + col) + 2 * pass;
+      __syncthreads();                    // the real kernel exchanges through LDS here
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        p[(size_t)(16 * slow + j) << 8] = expect0(((u64)g << 16) + ((16 * slow + j) << 8) + tile * 16 + col) + 2 * pass + 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (tid == 0) {
+      __hip_atomic_fetch_add(arrive + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u32 spins = 0;
+      while (ld_sc1(arrive + k) < 16) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 17) || ((spins & 255) == 0 && ld_sc1((gu32)&ctl->timeout[0]))) { atomicAdd(&ctl->timeout[0], 1u); break; }
+      }
+      spins_total += spins;
+    }
+    __syncthreads();
+    {
+      const u32 tile = member, w = tid >> 6, lane = tid & 63, pl = lane & 15, lw = lane >> 4;
+      const u32 row = tile * 16 + 4 * w + lw;
+      gptr p = base + (row << 8) + pl;
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) v[kk] = ld_row<LD>(p + 16 * kk);
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) wrong_row += v[kk] != expect0(((u64)g << 16) + (row << 8) + pl + 16 * kk) + 2 * pass + 1;
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) __builtin_nontemporal_store(v[kk] + 1, p + 16 * kk);
+    }
+  }
+  if (wrong_row) atomicAdd(&ctl->stats[10], wrong_row);
+  if (wrong_col) atomicAdd(&ctl->stats[11], wrong_col);
+  if (tid == 0 && spins_total) atomicAdd(&ctl->stats[8], spins_total);
+}
+
 // baseline: the two patterns as two launches (XCD-affine column order as in the library)
 __global__ __launch_bounds__(256) void k_col(u64 *data, u32 pass, u32 *wrong_) {
   const u32 b = blockIdx.x, g = (b >> 7) * 8 + (b & 7), tile = (b >> 3) & 15, tid = threadIdx.x, col = tid & 15, slow = tid >> 4;
@@ -158,6 +251,7 @@ __global__ __launch_bounds__(256) void k_col(u64 *data, u32 pass, u32 *wrong_) {
   for (int k = 0; k < 16; k++) v[k] = __builtin_nontemporal_load(p + ((size_t)(slow + 16 * k) << 8));
 #pragma unroll
   for (int k = 0; k < 16; k++) wrong += v[k] != expect0(((u64)g << 16) + ((slow + 16 * k) << 8) + tile * 16 + col) + 2 * pass;
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < 16; j++)
     __builtin_nontemporal_store(expect0(((u64)g << 16) + ((16 * slow + j) << 8) + tile * 16 + col) + 2 * pass + 1, p + ((size_t)(16 * slow + j) << 8));
@@ -257,5 +351,39 @@ int main(int argc, char **argv) {
         fflush(stdout);
         cfg++;
       }
+  // ---- team scheduler
+  {
+    const u32 iters = nlimbs + 2;
+    const size_t tbytes = sizeof(TeamCtl) + (size_t)2 * 8 * 8 * iters * 4;
+    char *tctl; CK(hipMalloc(&tctl, tbytes));
+    u32 *mail = (u32 *)(tctl + sizeof(TeamCtl)), *arrive = mail + (size_t)8 * 8 * iters;
+    std::vector<char> th(sizeof(TeamCtl));
+    for (int ld = 1; ld < 3; ld++)
+      for (u32 wgs_per_cu : {1u, 2u, 3u, 4u}) {
+        if (only >= 0 && only != cfg) { cfg++; continue; }
+        const u32 teams = wgs_per_cu * 32 / 16;
+        hipLaunchKernelGGL(k_init, dim3(4096), dim3(256), 0, 0, d, n);
+        float best = 1e9;
+        u32 wr = 0, wc = 0;
+        for (int rep = 0; rep < reps; rep++) {
+          CK(hipMemsetAsync(tctl, 0, tbytes, 0));
+          CK(hipEventRecord(e0));
+          if (ld == 1) hipLaunchKernelGGL(k_team<1>, dim3(256 * wgs_per_cu), dim3(256), 0, 0, d, (TeamCtl *)tctl, mail, arrive, nlimbs, teams, iters, (u32)rep);
+          else hipLaunchKernelGGL(k_team<2>, dim3(256 * wgs_per_cu), dim3(256), 0, 0, d, (TeamCtl *)tctl, mail, arrive, nlimbs, teams, iters, (u32)rep);
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          if (rep > 0 && ms < best) best = ms;
+          CK(hipMemcpy(th.data(), tctl, sizeof(TeamCtl), hipMemcpyDeviceToHost));
+          wr += ((const TeamCtl *)th.data())->stats[10]; wc += ((const TeamCtl *)th.data())->stats[11];
+        }
+        const TeamCtl *c = (const TeamCtl *)th.data();
+        printf("cfg %2d teams ld=%-4s wg/cu %u (teams/xcd %u)   %8.1f us  %6.0f GB/s algorithmic  wrong row/col loads %u/%u  wrong(final) %u  timeouts %u  spins %u  wg/xcd",
+               cfg, ldname[ld], wgs_per_cu, teams, best * 1e3, 2.0 * n * 8 / (best * 1e-3) / 1e9, wr, wc, report_check(reps), c->timeout[0], c->stats[8]);
+        for (int x = 0; x < 8; x++) printf(" %u", c->stats[x]);
+        printf("\n");
+        fflush(stdout);
+        cfg++;
+      }
+  }
   return 0;
 }
