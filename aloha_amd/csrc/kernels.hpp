@@ -114,5 +114,17 @@ hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *
                           bool inverse, const TileDesc *d_uni_tiles, uint32_t n_uni,
                           const TileDesc *d_glb_tiles, uint32_t n_glb, uint64_t *launches);
 
+// ---- CKKS encoder block (src/encoder), FP64: see encode_kernels.hip --------------------------------
+struct EncodeTables {      // per ring size N = 2^logn, n = N/2 slots; built by the host (vp_engine.cpp)
+  const double *w;         // [n/2][2]  exp(-2*pi*i*k/n)
+  const double *twist;     // [n][2]    exp(-i*pi*k/N)
+  const uint32_t *src;     // [n]       t -> slot index j, bit 31 = take conj(z_j)   (y_t of the derivation)
+};
+// nplain plaintexts of N doubles each (device) -> nplain*nlimbs limbs of N residues at d_out, coefficient
+// form; d_work: nplain*n complex doubles, needed only for logn > 14
+hipError_t encode(hipStream_t st, const double *d_re_im, const EncodeTables &tb, void *d_work, u64 *d_out,
+                  const u64 *d_moduli, uint32_t nlimbs, uint32_t nplain, unsigned logn, double scale,
+                  uint64_t *launches);
+
 }  // namespace k
 }  // namespace aloha

@@ -94,6 +94,11 @@ struct aloha_vp {
   std::vector<RowsKey> rows_cache;
   std::vector<std::pair<std::vector<uint8_t>, void *>> blobs;   // cached device copies of batched job arrays
   uint32_t chunk_limbs = 0;      // limbs per chunk of a batched transform (0 = whole batch; chunking did not pay)
+  // CKKS encoder: tables per ring size, staging buffers
+  struct EncTab { aloha::k::EncodeTables t{}; void *alloc = nullptr; };
+  std::map<unsigned, EncTab> enc_tables;
+  void *d_enc_in = nullptr, *d_enc_work = nullptr;
+  size_t enc_in_bytes = 0, enc_work_bytes = 0;
   aloha_vp_stats stats{};
   std::string err;
 };
@@ -353,6 +358,9 @@ void aloha_vp_destroy(aloha_vp *vp) {
   if (vp->d_primes) (void)hipFree(vp->d_primes);
   vp->plans.clear();
   for (auto &b : vp->blobs) if (b.second) (void)hipFree(b.second);
+  for (auto &e : vp->enc_tables) if (e.second.alloc) (void)hipFree(e.second.alloc);
+  if (vp->d_enc_in) (void)hipFree(vp->d_enc_in);
+  if (vp->d_enc_work) (void)hipFree(vp->d_enc_work);
   if (vp->own_stream && vp->stream) (void)hipStreamDestroy(vp->stream);
   delete vp;
 }
@@ -890,6 +898,77 @@ aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64
   key.jobs = jobs;
   vp->rows_cache.push_back(std::move(key));
   return run_transforms(vp, jobs, log_n, inverse != 0);
+}
+
+// CKKS encoder block: see encode_kernels.hip / include/aloha_vp.h.  Tables for ring size N (n = N/2):
+// w[k] = exp(-2 pi i k / n), twist[k] = exp(-i pi k / N) in long double, and the slot map of the
+// rotation group generated by 3 (run_rotate's k = 3^step, top_noaxilite_tb.sv:531).
+aloha_status aloha_vp_encode(aloha_vp *vp, int space, uint64_t dst_row, const double *host_re_im, uint32_t nplain,
+                             uint32_t log_n, const uint64_t *moduli, uint32_t nlimbs, double scale) {
+  if (!vp || !host_re_im || !moduli || !nplain || !nlimbs || !(scale > 0)) return ALOHA_ERR_ARG;
+  if (log_n < 10 || log_n > 16) return fail(vp, ALOHA_ERR_VL, "encode: log_n = %u", log_n);
+  for (uint32_t l = 0; l < nlimbs; l++)
+    if (!modulus_ok(moduli[l])) return fail(vp, ALOHA_ERR_MODULUS, "encode: modulus[%u] = %#llx", l, (u64)moduli[l]);
+  const size_t N = (size_t)1 << log_n, n = N / 2;
+  const uint64_t bytes = (uint64_t)nplain * nlimbs * N * 8;
+  u64 *dst = space_ptr(vp, space, dst_row, bytes);
+  if (!dst) return fail(vp, ALOHA_ERR_ADDR, "encode: %u x %u limbs at row %llu outside space %d", nplain, nlimbs, (u64)dst_row, space);
+  auto it = vp->enc_tables.find(log_n);
+  if (it == vp->enc_tables.end()) {
+    std::vector<double> host(n + 2 * n + n / 2 + 8);        // w (n/2 complex) | twist (n complex) | src (n u32)
+    double *w = host.data(), *tw = w + n;
+    uint32_t *src = reinterpret_cast<uint32_t *>(tw + 2 * n);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (size_t k = 0; k < n / 2; k++) {
+      const long double a = -2.0L * pi * (long double)k / (long double)n;
+      w[2 * k] = (double)cosl(a); w[2 * k + 1] = (double)sinl(a);
+    }
+    for (size_t k = 0; k < n; k++) {
+      const long double a = -pi * (long double)k / (long double)N;
+      tw[2 * k] = (double)cosl(a); tw[2 * k + 1] = (double)sinl(a);
+    }
+    uint64_t e = 1;
+    for (size_t j = 0; j < n; j++) {
+      if (e % 4 == 1) src[(e - 1) / 4] = (uint32_t)j;
+      else src[(2 * N - e - 1) / 4] = (uint32_t)j | 0x80000000u;
+      e = e * 3 % (2 * N);
+    }
+    aloha_vp::EncTab tab;
+    HIPCK(vp, hipMalloc(&tab.alloc, host.size() * 8));
+    HIPCK(vp, hipMemcpyAsync(tab.alloc, host.data(), host.size() * 8, hipMemcpyHostToDevice, vp->stream));
+    HIPCK(vp, hipStreamSynchronize(vp->stream));
+    tab.t.w = reinterpret_cast<const double *>(tab.alloc);
+    tab.t.twist = tab.t.w + n;
+    tab.t.src = reinterpret_cast<const uint32_t *>(tab.t.twist + 2 * n);
+    it = vp->enc_tables.emplace(log_n, tab).first;
+  }
+  const size_t in_bytes = (size_t)nplain * N * 8, work_bytes = log_n > 14 ? (size_t)nplain * n * 16 : 0;
+  if (in_bytes > vp->enc_in_bytes) {
+    HIPCK(vp, hipStreamSynchronize(vp->stream));
+    if (vp->d_enc_in) (void)hipFree(vp->d_enc_in);
+    vp->d_enc_in = nullptr; vp->enc_in_bytes = 0;
+    HIPCK(vp, hipMalloc(&vp->d_enc_in, in_bytes));
+    vp->enc_in_bytes = in_bytes;
+  }
+  if (work_bytes > vp->enc_work_bytes) {
+    HIPCK(vp, hipStreamSynchronize(vp->stream));
+    if (vp->d_enc_work) (void)hipFree(vp->d_enc_work);
+    vp->d_enc_work = nullptr; vp->enc_work_bytes = 0;
+    HIPCK(vp, hipMalloc(&vp->d_enc_work, work_bytes));
+    vp->enc_work_bytes = work_bytes;
+  }
+  const void *d_moduli = nullptr;
+  aloha_status s = device_blob(vp, moduli, (size_t)nlimbs * 8, &d_moduli);
+  if (s) return s;
+  HIPCK(vp, hipMemcpyAsync(vp->d_enc_in, host_re_im, in_bytes, hipMemcpyHostToDevice, vp->stream));
+  uint64_t launches = 0;
+  hipError_t e = aloha::k::encode(vp->stream, reinterpret_cast<const double *>(vp->d_enc_in), it->second.t,
+                                  vp->d_enc_work, dst, reinterpret_cast<const u64 *>(d_moduli), nlimbs, nplain, log_n,
+                                  scale, &launches);
+  vp->stats.kernel_launches += launches;
+  if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "encode launch failed: %s", hipGetErrorString(e));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));         // the host buffer is borrowed for the call only
+  return ALOHA_OK;
 }
 
 aloha_status aloha_find_psi(uint64_t q, uint32_t log_n, uint64_t *psi) {

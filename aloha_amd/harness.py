@@ -5,11 +5,13 @@ Mirrors ``sim/top/top_noaxilite_tb.sv``: the op-list format (``parse_op`` :249-2
 (:419-448), ``run_load_cipher`` / ``run_store_cipher`` (:450-496), ``run_mul_plain`` /
 ``run_hom_add`` / ``run_rotate`` (:522-532) and the per-op dump (``run`` :596-638).
 
-The AXI DMA and DDR model are replaced by host arrays; the CKKS encoder block
-(``src/encoder``, floating point on closed Xilinx IP) is out of scope, so ``encode`` takes
-the encoder's *output* (two limbs, what the test bench dumps as ``inst_K_0_out.txt``) and
-runs the ``encode_post`` program on it exactly as ``run_encode`` does after the hardware
-encoder finishes (:446-447).
+The AXI DMA and DDR model are replaced by host arrays.  ``encode`` runs the encoder block
+(``vp.encode``: the reference's software-model convention in double precision, see
+``include/aloha_vp.h``) on a cleartext registered in ``dram_cleartext``; to replay the RTL's
+own chains -- whose single-precision encoder differs from the model in every coefficient -- it
+instead takes the encoder's *output* from ``dram_encoder`` (two limbs, what the test bench
+dumps as ``inst_K_0_out.txt``).  Either way ``encode_post`` follows, as in ``run_encode``
+(:446-447).
 
 ``vp`` is any object with ``write/read/load_isram/run/sync`` (``aloha_amd.vp.VP``).
 """
@@ -69,7 +71,8 @@ class TestBench:
     __test__ = False  # not a pytest class
 
     def __init__(self, vp, n: int = 8192, limbs: int = 2, specials: int = 1,
-                 pcs: Optional[Dict[str, int]] = None):
+                 pcs: Optional[Dict[str, int]] = None, moduli: Optional[Sequence[int]] = None,
+                 scale: float = 2.0 ** 38):
         self.vp = vp
         self.n = n
         self.limbs = limbs
@@ -81,6 +84,9 @@ class TestBench:
                            "hom_add": isa.PC_HOM_ADD, "keyswitch": isa.PC_KEYSWITCH}
         self.dram_ct: Dict[int, np.ndarray] = {}        # DRAM_VP_BASE + dram_addr -> ciphertext
         self.dram_encoder: Dict[int, np.ndarray] = {}   # encode slot -> encoder output (2 limbs)
+        self.dram_cleartext: Dict[int, np.ndarray] = {} # encode slot -> N doubles, (re, im) interleaved slots
+        self.moduli = list(moduli) if moduli is not None else None   # ciphertext primes, for the encoder block
+        self.scale = scale
         self.dump: Optional[Callable[[int, str, np.ndarray], None]] = None
 
     # -- init (:685-716) -------------------------------------------------------------------
@@ -114,9 +120,16 @@ class TestBench:
         return self.vp.read(SPM, row, self.ct_words)
 
     def run_encode(self, inst_id: int, dest: int, dram_addr: int) -> None:
-        enc = np.ascontiguousarray(self.dram_encoder[dram_addr], dtype=np.uint64)
-        assert enc.size == self.limbs * self.n
-        self.vp.write(SPM, dest, enc)
+        if dram_addr in self.dram_encoder:
+            enc = np.ascontiguousarray(self.dram_encoder[dram_addr], dtype=np.uint64)
+            assert enc.size == self.limbs * self.n
+            self.vp.write(SPM, dest, enc)
+        else:                                                                    # DMA_CMD_ENCODE (:424-431)
+            if self.moduli is None:
+                raise ValueError("TestBench(moduli=...) is needed to run the encoder block")
+            z = np.ascontiguousarray(self.dram_cleartext[dram_addr], dtype=np.float64)
+            assert z.size == self.n
+            self.vp.encode(SPM, dest, z, self.n.bit_length() - 1, self.moduli[:self.limbs], self.scale)
         if self.dump:
             self.dump(inst_id, "_0", self.copy_spm(dest))                       # dump_sub_poly (:444-445)
         self.run_vp(dest, dest, 0, 0, 0, self.pcs["encode_post"])               # :447

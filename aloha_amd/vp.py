@@ -35,7 +35,7 @@ EXPORTS = ["aloha_vp_abi_version", "aloha_status_string", "aloha_vp_create", "al
            "aloha_vp_last_error", "aloha_vp_write", "aloha_vp_read", "aloha_vp_device_ptr",
            "aloha_vp_load_isram", "aloha_vp_load_isram_hex", "aloha_vp_run", "aloha_vp_sync",
            "aloha_vp_ntt_rows", "aloha_find_psi", "aloha_nth_prime", "aloha_vp_get_stats",
-           "aloha_vp_peek_vreg"]
+           "aloha_vp_peek_vreg", "aloha_vp_encode"]
 
 
 class AlohaError(RuntimeError):
@@ -90,6 +90,7 @@ def load_library() -> C.CDLL:
     L.aloha_nth_prime.restype = u64; L.aloha_nth_prime.argtypes = [u32, u32]
     L.aloha_vp_get_stats.restype = i; L.aloha_vp_get_stats.argtypes = [p, C.POINTER(_Stats)]
     L.aloha_vp_peek_vreg.restype = i; L.aloha_vp_peek_vreg.argtypes = [p, u32, p, u64]
+    L.aloha_vp_encode.restype = i; L.aloha_vp_encode.argtypes = [p, i, u64, p, u32, u32, p, u32, C.c_double]
     _lib = L
     return L
 
@@ -186,6 +187,16 @@ class VP:
         m = np.ascontiguousarray(moduli, dtype=np.uint64)
         self._chk(self._L.aloha_vp_ntt_rows(self._h, space, dst_row, src_row, log_n, m.ctypes.data,
                                             m.size, int(bool(inverse))))
+
+    # -- CKKS encoder block (src/encoder; run_encode's DMA command, top_noaxilite_tb.sv:419-448) -----
+    def encode(self, space: int, dst_row: int, re_im, log_n: int, moduli: Sequence[int],
+               scale: float = 2.0 ** 38) -> None:
+        """``re_im``: one or more cleartexts of N doubles (N/2 slots, (re, im) interleaved) ->
+        ``len(moduli)`` coefficient-form limbs per cleartext at ``dst_row``."""
+        z = np.ascontiguousarray(re_im, dtype=np.float64).reshape(-1, 1 << log_n)
+        m = np.ascontiguousarray(moduli, dtype=np.uint64)
+        self._chk(self._L.aloha_vp_encode(self._h, space, dst_row, z.ctypes.data, z.shape[0], log_n,
+                                          m.ctypes.data, m.size, float(scale)))
 
     # -- introspection ------------------------------------------------------------------------
     def stats(self) -> dict:

@@ -108,6 +108,20 @@ aloha_status aloha_vp_sync(aloha_vp *vp);   /* `done` */
 aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64_t src_row,
                                uint32_t log_n, const uint64_t *moduli, uint32_t count, int inverse);
 
+/* ---- CKKS encoder block (replaces src/encoder; encoder_top.sv:12-52, DMA command of the
+ * test-bench task run_encode, top_noaxilite_tb.sv:419-448) -------------------------------------------
+ * nplain cleartexts of N = 2^log_n doubles each -- N/2 complex slots, (re, im) interleaved, exactly the
+ * DRAM image the test bench hands the encoder -- become nplain * nlimbs limbs in COEFFICIENT form at
+ * dst_row (plaintext p, limb l at dst_row + (p*nlimbs + l)*(N/128), under moduli[l]); the caller then
+ * runs encode_post / aloha_vp_ntt_rows, as run_encode does.  Convention of the reference's software
+ * model (tv/ encode pairs): m(zeta^(3^j)) = scale * z_j, scale = 2^38 in tv/, round to nearest,
+ * negative coefficients stored as q - |x|.  Double precision; agreement with the golden pairs is by
+ * tolerance (their cleartexts carry 6 digits), and the RTL's own single-precision results differ from
+ * its model everywhere.  |scale * z| must stay below 2^62. */
+aloha_status aloha_vp_encode(aloha_vp *vp, int space, uint64_t dst_row, const double *host_re_im,
+                             uint32_t nplain, uint32_t log_n, const uint64_t *moduli, uint32_t nlimbs,
+                             double scale);
+
 /* ---- parameters ------------------------------------------------------------------------------ */
 /* minimal primitive 2N-th root of unity mod q -- the rule behind the reference's hard-coded
  * psi values (tf_rom_generator.sv:75) */

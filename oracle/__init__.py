@@ -198,6 +198,13 @@ class OracleVP:
     def sync(self):
         pass
 
+    def encode(self, space, dst_row, re_im, log_n, moduli, scale=2.0 ** 38):
+        """The encoder block (oracle/ckks_encode.py), same call as ``aloha_amd.vp.VP.encode``."""
+        from . import ckks_encode
+        z = np.ascontiguousarray(re_im, dtype=np.float64).reshape(-1, 1 << log_n)
+        out = np.concatenate([ckks_encode.encode(zz, log_n, moduli, scale).reshape(-1) for zz in z])
+        self.write(space, dst_row, out)
+
     def peek_vreg(self, r, n):
         out = np.empty(n, np.uint64)
         self._chk(lib().orc_vp_peek_vreg(self._h, r, out.ctypes.data, n))

@@ -101,6 +101,29 @@ def main() -> int:
     m2["case3_expected_result"] = put("case2/case3_expected_result.bin", final)
     man["case2"] = m2
 
+    # ---- CKKS encoder pairs of the software model (cleartext -> coefficient-form plaintext) -----
+    # Cleartexts are N doubles ((re, im) interleaved slots) of which only a short prefix is non-zero:
+    # kept in the manifest as [index, value] pairs.  Expected outputs: *_fft_mod (before the NTT);
+    # case0 ships only the NTT-domain plaintext, kept as such.
+    def cleartext(path):
+        z = np.loadtxt(path)
+        assert z.size == N
+        nz = np.nonzero(z)[0]
+        return {"n": N, "nonzero": [[int(i), float(z[i])] for i in nz]}
+    enc: dict = {}
+    for case, k in (("case1_8_8", 1), ("case1_8_8", 2), ("case2_16_16", 13), ("case2_16_16", 14)):
+        d = os.path.join(tv, case)
+        short = case.split("_")[0]
+        key = f"{short}/kernel{k}"
+        ent = {"cleartext": cleartext(os.path.join(d, f"kernel{k}_cleartext_before_encode_re_im.txt"))}
+        rel = f"{short}/kernel{k}_pt_after_encode_fft_mod.bin"
+        ent["fft_mod"] = put(rel, read_tv(os.path.join(d, f"kernel{k}_pt_after_encode_fft_mod.txt")))
+        enc[key] = ent
+    ent = {"cleartext": cleartext(os.path.join(c0, "kernel2_cleartext_before_encode_re_im.txt"))}
+    ent["ntt"] = put("case0/kernel2_pt_after_encode.bin", read_tv(os.path.join(c0, "kernel2_pt_after_encode.txt")))
+    enc["case0/kernel2"] = ent
+    man["encode"] = enc
+
     # ---- instruction-ROM images the test bench loads ($readmemh data, inst_rom.v:32-35) -------
     # Stored as packed uint32 triplets (inst, imm_hi, imm_lo) -- the four micro-programs that
     # the system test runs (isram_file_generator.sv:27-30).  They are test INPUTS: the product
