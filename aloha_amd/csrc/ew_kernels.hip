@@ -124,6 +124,34 @@ __global__ __launch_bounds__(256) void dot_kernel(DotArgs g, uint32_t n2) {
   }
 }
 
+__global__ __launch_bounds__(256) void dot_batch_kernel(const DotArgs *__restrict__ jobs, uint32_t n2) {
+  const DotArgs *g = &jobs[blockIdx.y];                      // wave-uniform: operand pointers come through scalar loads
+  const u64 q = g->m.q, mu = g->m.mu;
+  const int nterms = g->nterms;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+    u64x2 acc{0, 0};
+    if (g->init) {
+      acc = reinterpret_cast<const u64x2 *>(g->init)[i];
+      acc.x = csub(acc.x, q); acc.y = csub(acc.y, q);
+    }
+    int t = 0;
+    for (; t + 1 < nterms; t += 2) {                         // two terms per trip: four 16-byte loads in flight
+      const u64x2 a0 = reinterpret_cast<const u64x2 *>(g->a[t])[i], b0 = reinterpret_cast<const u64x2 *>(g->b[t])[i];
+      const u64x2 a1 = reinterpret_cast<const u64x2 *>(g->a[t + 1])[i], b1 = reinterpret_cast<const u64x2 *>(g->b[t + 1])[i];
+      acc.x = addmod(acc.x, mulmod_barrett(csub(a0.x, q), csub(b0.x, q), q, mu), q);
+      acc.y = addmod(acc.y, mulmod_barrett(csub(a0.y, q), csub(b0.y, q), q, mu), q);
+      acc.x = addmod(acc.x, mulmod_barrett(csub(a1.x, q), csub(b1.x, q), q, mu), q);
+      acc.y = addmod(acc.y, mulmod_barrett(csub(a1.y, q), csub(b1.y, q), q, mu), q);
+    }
+    if (t < nterms) {
+      const u64x2 a0 = reinterpret_cast<const u64x2 *>(g->a[t])[i], b0 = reinterpret_cast<const u64x2 *>(g->b[t])[i];
+      acc.x = addmod(acc.x, mulmod_barrett(csub(a0.x, q), csub(b0.x, q), q, mu), q);
+      acc.y = addmod(acc.y, mulmod_barrett(csub(a0.y, q), csub(b0.y, q), q, mu), q);
+    }
+    reinterpret_cast<u64x2 *>(g->d)[i] = acc;
+  }
+}
+
 inline uint32_t grid_for(uint32_t work_items) {
   uint32_t g = (work_items + 255) / 256;
   return g > 2048 ? 2048 : (g ? g : 1);
@@ -171,6 +199,15 @@ hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsig
 hipError_t dot(hipStream_t st, const DotArgs &args, uint32_t n) {
   const uint32_t n2 = n / 2;
   hipLaunchKernelGGL(dot_kernel, dim3(grid_for(n2)), dim3(256), 0, st, args, n2);
+  return hipGetLastError();
+}
+
+hipError_t dot_batch(hipStream_t st, const DotArgs *d_jobs, uint32_t njobs, uint32_t n) {
+  if (!njobs) return hipSuccess;
+  const uint32_t n2 = n / 2;
+  uint32_t gx = grid_for(n2);
+  while (gx > 16 && (uint64_t)gx * njobs > 8192) gx /= 2;    // plenty of workgroups already: longer grid-stride loops instead
+  hipLaunchKernelGGL(dot_batch_kernel, dim3(gx, njobs), dim3(256), 0, st, d_jobs, n2);
   return hipGetLastError();
 }
 

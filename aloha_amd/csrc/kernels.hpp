@@ -52,7 +52,7 @@ hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsig
 
 // d = init + sum_t a[t] .* b[t]  (mod q), up to kDotTerms terms per launch: the key-switch
 // inner product (keyswitch.mem:46-79) as ONE pass over its operands.
-constexpr int kDotTerms = 32;
+constexpr int kDotTerms = 64;
 struct DotArgs {
   const u64 *a[kDotTerms];
   const u64 *b[kDotTerms];
@@ -62,6 +62,9 @@ struct DotArgs {
   int nterms, pad;
 };
 hipError_t dot(hipStream_t st, const DotArgs &args, uint32_t n);
+// many independent dot products in ONE launch (blockIdx.y = job): all accumulators of a key-switch
+// phase together fill the chip, where a single one occupies 128 workgroups
+hipError_t dot_batch(hipStream_t st, const DotArgs *d_jobs, uint32_t njobs, uint32_t n);
 
 // ---- transforms --------------------------------------------------------------------------
 // Device-resident twiddle set of one (q, N); tables hold (w, floor(w*2^64/q)) pairs.

@@ -138,7 +138,16 @@ aloha_status vl_logn(uint64_t vl_bits, unsigned max_logn, unsigned *logn) {
   return ALOHA_ERR_VL;                               // ntt_fsm.sv:59-65 admits log2 N in 10..16
 }
 
-bool modulus_ok(uint64_t q) { return q > (1ull << 59) && q < (1ull << 60) && aloha::nt::is_prime(q); }
+// primality is checked once per value and thread: programs set the same few moduli over and over
+bool modulus_ok(uint64_t q) {
+  if (!(q > (1ull << 59) && q < (1ull << 60))) return false;
+  thread_local std::vector<uint64_t> known;
+  for (uint64_t k : known) if (k == q) return true;
+  if (!aloha::nt::is_prime(q)) return false;
+  if (known.size() >= 4096) known.clear();
+  known.push_back(q);
+  return true;
+}
 
 ModCtx modctx(uint64_t q) { return ModCtx{q, 0 - q, aloha::nt::barrett_mu(q), (1ull << 59) / ((q >> 32) + 1)}; }
 
@@ -522,11 +531,24 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   const bool fuse = !(vp->flags & ALOHA_FLAG_NO_FUSION);
   const u64 *alias[ALOHA_NVREG] = {nullptr};                // non-null: the register's value is memory at this address
   // Pending batch: deferred memory-to-memory jobs of ONE kind, launched together by flush().
-  enum { PK_NONE, PK_NTT, PK_AUT, PK_EW } pend_kind = PK_NONE;
+  enum { PK_NONE, PK_NTT, PK_AUT, PK_EW, PK_DOT } pend_kind = PK_NONE;
   std::vector<LimbJob> batch;                               // PK_NTT
   std::vector<aloha::k::AutJob> aut_batch;                  // PK_AUT
+  std::vector<aloha::k::DotArgs> dot_batch;                 // PK_DOT: lazy dot products stored straight to memory
+  const u64 *dot_w_lo = nullptr, *dot_w_hi = nullptr, *dot_a_lo = nullptr, *dot_a_hi = nullptr, *dot_b_lo = nullptr,
+            *dot_b_hi = nullptr;                           // boxes of the pending sums' destinations / first / second operands
   std::vector<aloha::k::EwJob> ew_batch;                    // PK_EW
   std::vector<std::pair<const u64 *, const u64 *>> pend_rw; // (read range, written range) of every pending job
+  // bounding boxes of the pending reads / writes: a new job that misses both boxes conflicts with
+  // nothing, so loops over disjoint regions (the usual shape) join in O(1) instead of O(pending)
+  const u64 *box_r_lo = nullptr, *box_r_hi = nullptr, *box_w_lo = nullptr, *box_w_hi = nullptr;
+  auto note_rw = [&](const u64 *r, const u64 *w, size_t n) {
+    pend_rw.emplace_back(r, w);
+    if (r) { if (!box_r_lo || r < box_r_lo) box_r_lo = r; if (!box_r_hi || r + n > box_r_hi) box_r_hi = r + n; }
+    if (!box_w_lo || w < box_w_lo) box_w_lo = w;
+    if (!box_w_hi || w + n > box_w_hi) box_w_hi = w + n;
+  };
+  auto hits = [](const u64 *p, size_t n, const u64 *lo, const u64 *hi) { return p && lo && p < hi && lo < p + n; };
   bool batch_inv = false;
   unsigned batch_logn = 0;
   // Lazy dot products: register r stands for sum_t a_t .* b_t (mod lazy_q[r]) over memory
@@ -556,7 +578,18 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "ew_batch: %s", hipGetErrorString(e));
       }
     }
-    batch.clear(); aut_batch.clear(); ew_batch.clear(); pend_rw.clear();
+    else if (pend_kind == PK_DOT && !dot_batch.empty()) {
+      const void *dj = nullptr;
+      s = device_blob(vp, dot_batch.data(), dot_batch.size() * sizeof(dot_batch[0]), &dj);
+      if (!s) {
+        hipError_t e = aloha::k::dot_batch(st, (const aloha::k::DotArgs *)dj, (uint32_t)dot_batch.size(), 1u << batch_logn);
+        vp->stats.kernel_launches++;
+        if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "dot_batch: %s", hipGetErrorString(e));
+      }
+    }
+    batch.clear(); aut_batch.clear(); ew_batch.clear(); dot_batch.clear(); pend_rw.clear();
+    box_r_lo = box_r_hi = box_w_lo = box_w_hi = nullptr;
+    dot_w_lo = dot_w_hi = dot_a_lo = dot_a_hi = dot_b_lo = dot_b_hi = nullptr;
     pend_kind = PK_NONE;
     return s;
   };
@@ -564,6 +597,9 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   auto can_join = [&](int kind, unsigned logn_, const u64 *a, const u64 *b, const u64 *z, size_t n) -> bool {
     if (pend_kind == PK_NONE) return true;
     if (pend_kind != kind || batch_logn != logn_) return false;
+    if (!hits(z, n, box_w_lo, box_w_hi) && !hits(z, n, box_r_lo, box_r_hi) && !hits(a, n, box_w_lo, box_w_hi) &&
+        !hits(b, n, box_w_lo, box_w_hi))
+      return true;
     for (const auto &rw : pend_rw) {
       const u64 *r = rw.first, *w = rw.second;
       if (overlap(z, w, n) || (r && overlap(z, r, n))) return false;          // WAW / WAR
@@ -727,8 +763,8 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           aloha::k::EwJob jb{};
           jb.d = z; jb.a = a; jb.b = b ? b : a; jb.s = s; jb.s_shoup = aloha::nt::shoup(s, q); jb.m = modctx(q); jb.op = (int)op;
           ew_batch.push_back(jb);
-          pend_rw.emplace_back(a, z);
-          if (b) pend_rw.emplace_back(b, z);
+          note_rw(a, z, n);
+          if (b) note_rw(b, z, n);
           pend_kind = PK_EW; batch_logn = logn;
           alias[vd] = nullptr;
           pc++; vp->stats.instructions++;                          // the vse is done
@@ -763,7 +799,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
             jb.k_inv = (uint32_t)(kinv & (n - 1));
           }
           aut_batch.push_back(jb);
-          pend_rw.emplace_back(in, z);
+          note_rw(in, z, n);
           pend_kind = PK_AUT; batch_logn = logn;
           alias[vd] = nullptr;
           pc++; vp->stats.instructions++;
@@ -806,7 +842,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
           if (!joinable()) ALOHA_RUN_CK(flush());
           batch.push_back(LimbJob{src, z, slot, 0});
-          pend_rw.emplace_back(src, z);
+          note_rw(src, z, n);
           pend_kind = PK_NTT; batch_inv = inv; batch_logn = logn;
           alias[vd] = nullptr;
           pc++; vp->stats.instructions++;
@@ -838,6 +874,42 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
             terms.swap(lazy[vs1]);                                 // keep before_mem_write from evaluating it twice
             ALOHA_RUN_CK(before_mem_write(p, n, pc + 1));
             lazy[vs1].swap(terms);
+            if (lazy[vs1].size() <= (size_t)aloha::k::kDotTerms) {
+              // deferred: all such sums of a loop go out as ONE launch.  A pending dot job's writes are
+              // its `d`; its reads are its operands: the new job may neither read nor overwrite a
+              // pending destination, nor overwrite a pending operand.
+              auto joinable = [&]() {
+                if (pend_kind == PK_NONE) return true;
+                if (pend_kind != PK_DOT || batch_logn != logn) return false;
+                bool clear = !hits(p, n, dot_w_lo, dot_w_hi) && !hits(p, n, dot_a_lo, dot_a_hi) && !hits(p, n, dot_b_lo, dot_b_hi);
+                for (const auto &t : lazy[vs1])
+                  clear = clear && !hits(t.first, n, dot_w_lo, dot_w_hi) && !hits(t.second, n, dot_w_lo, dot_w_hi);
+                if (clear) return true;
+                for (const auto &g : dot_batch) {
+                  if (overlap(p, g.d, n)) return false;
+                  for (int t = 0; t < g.nterms; t++)
+                    if (overlap(p, g.a[t], n) || overlap(p, g.b[t], n)) return false;
+                  for (const auto &t : lazy[vs1])
+                    if (overlap(t.first, g.d, n) || overlap(t.second, g.d, n)) return false;
+                }
+                return true;
+              };
+              if (!joinable()) ALOHA_RUN_CK(flush());
+              aloha::k::DotArgs g{};
+              g.nterms = (int)lazy[vs1].size();
+              for (int t = 0; t < g.nterms; t++) { g.a[t] = lazy[vs1][t].first; g.b[t] = lazy[vs1][t].second; }
+              g.init = nullptr; g.d = p; g.m = modctx(lazy_q[vs1]);
+              dot_batch.push_back(g);
+              auto grow = [&](const u64 *x, const u64 *&lo, const u64 *&hi) {
+                if (!lo || x < lo) lo = x;
+                if (!hi || x + n > hi) hi = x + n;
+              };
+              grow(p, dot_w_lo, dot_w_hi);
+              for (int t = 0; t < g.nterms; t++) { grow(g.a[t], dot_a_lo, dot_a_hi); grow(g.b[t], dot_b_lo, dot_b_hi); }
+              pend_kind = PK_DOT; batch_logn = logn;
+              lazy[vs1].clear();
+              break;
+            }
             ALOHA_RUN_CK(materialise(vs1, p, n));                  // the dot product lands in memory directly
             break;
           }

@@ -11,6 +11,9 @@ instead of the 32-entry register file, and with the limbs partitioned over ``wor
     exchange ALL-GATHER of the coefficient-form digits D[0..L-1]           (keyswitch.mem:4-43)
     phase 2  per owned modulus j (ciphertext primes and P):
                  acc_c[j] = sum_d NTT_j(D[d] mod m_j) * KSK[j][d][c]        (keyswitch.mem:46-79)
+             as two loops: ALL Mr*L transforms (one batched launch pair), then ALL 2*Mr inner
+             products (one batched launch per program; the products are split over several
+             programs when they exceed the 4096-word instruction ROM)
     phase 3  owner of P       :  t_c = iNTT(acc_c[P]) + floor(P/2)          (keyswitch.mem:80-83)
     exchange BROADCAST of t_0, t_1 from P's owner
     phase 4  per owned j < L  :  r_c = (acc_c[j] - NTT_j(t_c - floor(P/2))) * P^-1
@@ -41,7 +44,7 @@ Rank-local SPM layout, in limb slots of N/128 rows from ``base_row``:
     T     [2]     mod-down terms                         (broadcast target)
     OUT   [2*Lr]  result: c0 then c1 of the owned primes
     S1/S2 [2*Lr]  scratch (phase 1: coefficient forms; phase 4: mod-down intermediates)
-    SD    [L]     scratch (phase 2: digits in NTT form under the current modulus)
+    SD    [Mr*L]  scratch (phase 2: every digit in NTT form under every owned modulus)
 Rank-local KSK layout: limb ((jl*L + d)*2 + c) for owned modulus jl, digit d, component c.
 """
 from __future__ import annotations
@@ -92,7 +95,7 @@ class Layout:
         self.out = s; s += 2 * self.Lr
         self.s1 = s; s += 2 * self.Lr
         self.s2 = s; s += 2 * self.Lr
-        self.sd = s; s += L
+        self.sd = s; s += L * self.Mr
         self.slots = s
 
     # slot -> absolute row / byte offset helpers
@@ -139,21 +142,35 @@ def program_digits(lo: Layout) -> List[str]:
     return out + ["break"]
 
 
-def program_inner(lo: Layout, jl: int) -> List[str]:
-    """Phase 2 for the jl-th owned modulus."""
-    j = lo.owned_all[jl]
-    out = [f"vsetvl {64 * lo.n:#x}"] + _setq(lo.modulus(j))
-    for d in range(lo.L):                                       # every digit under this modulus, NTT form
-        out += [f"vle v0, abs+{lo.off(lo.dig_slot(d)):#x}", "vntt v2, v0", f"vse v2, abs+{lo.off(lo.sd + d):#x}"]
-    for c in range(2):                                          # inner product with the key, per component
-        acc = 6 + 2 * c                                         # v6, v8 (even bank)
+def program_digit_transforms(lo: Layout, jls: Sequence[int]) -> List[str]:
+    """Phase 2a for the owned moduli ``jls``: every digit under each of them, NTT form, into SD[jl*L + d]."""
+    out = [f"vsetvl {64 * lo.n:#x}"]
+    for jl in jls:
+        j = lo.owned_all[jl]
+        out += _setq(lo.modulus(j))
         for d in range(lo.L):
-            out += [f"vle v0, abs+{lo.off(lo.sd + d):#x}", f"vle v1, ksk+{((jl * lo.L + d) * 2 + c) * 8 * lo.n:#x}"]
-            if d == 0:
-                out.append(f"vfqmul.vv v{acc}, v0, v1")
-            else:
-                out += ["vfqmul.vv v3, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v3"]
-        out.append(f"vse v{acc}, abs+{lo.off(lo.acc + 2 * jl + c):#x}")
+            out += [f"vle v0, abs+{lo.off(lo.dig_slot(d)):#x}", "vntt v2, v0", f"vse v2, abs+{lo.off(lo.sd + jl * lo.L + d):#x}"]
+    return out + ["break"]
+
+
+def inner_words_per_modulus(lo: Layout) -> int:
+    return 2 + 2 * (4 * lo.L)                                   # vsetq, vsetiq, per component: L x (vle, vle, mul[, add]) + vse
+
+
+def program_inner(lo: Layout, jls: Sequence[int]) -> List[str]:
+    """Phase 2b for the owned moduli with local indices ``jls``: the digit-by-key inner products."""
+    out = [f"vsetvl {64 * lo.n:#x}"]
+    for jl in jls:
+        out += _setq(lo.modulus(lo.owned_all[jl]))
+        for c in range(2):                                      # inner product with the key, per component
+            acc = 6 + 2 * c                                     # v6, v8 (even bank)
+            for d in range(lo.L):
+                out += [f"vle v0, abs+{lo.off(lo.sd + jl * lo.L + d):#x}", f"vle v1, ksk+{((jl * lo.L + d) * 2 + c) * 8 * lo.n:#x}"]
+                if d == 0:
+                    out.append(f"vfqmul.vv v{acc}, v0, v1")
+                else:
+                    out += ["vfqmul.vv v3, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v3"]
+            out.append(f"vse v{acc}, abs+{lo.off(lo.acc + 2 * jl + c):#x}")
     return out + ["break"]
 
 
@@ -283,7 +300,11 @@ class ShardedKeySwitch:
         lo = self.lo
         asm = lambda lines: isa.assemble("\n".join(lines))
         self._p_digits = asm(program_digits(lo))
-        self._p_inner = [asm(program_inner(lo, jl)) for jl in range(lo.Mr)]
+        def groups(words_per_modulus):                          # owned moduli per program, by ROM capacity
+            per = max(1, (isa.IRAM_DEPTH - 2) // words_per_modulus)
+            return [list(range(g, min(g + per, lo.Mr))) for g in range(0, lo.Mr, per)]
+        self._p_inner = [asm(program_digit_transforms(lo, g)) for g in groups(2 + 3 * lo.L)] + \
+                        [asm(program_inner(lo, g)) for g in groups(inner_words_per_modulus(lo))]
         self._p_terms = asm(program_moddown_terms(lo)) if lo.L in lo.owned_all else None
         self._p_finish = asm(program_finish(lo))
         progs = [self._p_digits, self._p_finish] + ([self._p_terms] if self._p_terms is not None else [])

@@ -118,7 +118,9 @@ def aut_batch():
 
 
 if __name__ == "__main__":
-    res = {"config2_ntt_n4096": config2(), "config3_polymul_n16384_8limbs": config3(),
-           "config4_keyswitch_n65536_L24": config45(24), "config5_keyswitch_n65536_L32": config45(32),
-           "config5_automorphism_batch": aut_batch()}
+    todo = {"config2_ntt_n4096": config2, "config3_polymul_n16384_8limbs": config3,
+            "config4_keyswitch_n65536_L24": lambda: config45(24), "config5_keyswitch_n65536_L32": lambda: config45(32),
+            "config5_automorphism_batch": aut_batch}
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]           # e.g. `config4` (prefix match), for profiling runs
+    res = {k: f() for k, f in todo.items() if not only or any(k.startswith(o) for o in only)}
     print(json.dumps(res, indent=1))
