@@ -19,6 +19,14 @@ instead of the 32-entry register file, and with the limbs partitioned over ``wor
     phase 4  per owned j < L  :  r_c = (acc_c[j] - NTT_j(t_c - floor(P/2))) * P^-1
                                  out_0[j] = R[j] + r_0,  out_1[j] = r_1      (keyswitch.mem:84-121)
 
+The same phases 2-4 relinearise a ciphertext product (BASELINE config 4, "HMult + relinearisation";
+no reference program exists): phase 1 becomes the tensor product
+
+    phase 1m per owned prime j :  d0 = a0*b0,  d1 = a0*b1 + a1*b0,  d2 = a1*b1   (NTT domain),
+                                  D[j] = iNTT(d2)                                  (digit j)
+
+and phase 4 adds d0, d1 where the rotation adds the rotated c0: out = (d0 + r_0, d1 + r_1).
+
 Every phase is an HE-ISA program run by the engine (``VP.run``); only the two exchanges go
 through ``torch.distributed`` (RCCL over xGMI on GPUs, gloo in the CPU tests).  With
 ``world == 1`` this is the single-GPU key-switch for any L.
@@ -39,7 +47,9 @@ subtraction.
 Rank-local SPM layout, in limb slots of N/128 rows from ``base_row``:
     CT_IN [2*Lr]  c0 of the owned primes, then c1        (Lr = owned ciphertext primes)
     DIG   [G*Dr]  all digits, grouped by owner           (Dr = ceil(L/G); all-gather target)
-    ROT   [Lr]    rotated c0, NTT form
+    ROT   [Lr]    rotated c0, NTT form  (product: d0)
+    BASE1 [Lr]    product only: d1
+    CT_B  [2*Lr]  product only: the second operand, c0 then c1
     ACC   [2*Mr]  inner products of the owned moduli     (Mr = owned moduli incl. P if owned)
     T     [2]     mod-down terms                         (broadcast target)
     OUT   [2*Lr]  result: c0 then c1 of the owned primes
@@ -90,6 +100,8 @@ class Layout:
         self.ct_in = s; s += 2 * self.Lr
         self.dig = s; s += self.world * self.Dr
         self.rot = s; s += self.Lr
+        self.base1 = s; s += self.Lr
+        self.ct_b = s; s += 2 * self.Lr
         self.acc = s; s += 2 * self.Mr
         self.t = s; s += 2
         self.out = s; s += 2 * self.Lr
@@ -142,6 +154,26 @@ def program_digits(lo: Layout) -> List[str]:
     return out + ["break"]
 
 
+def program_tensor(lo: Layout) -> List[str]:
+    """Phase 1 of the ciphertext product: a = CT_IN, b = CT_B (NTT form), both (c0, c1)."""
+    out = [f"vsetvl {64 * lo.n:#x}"]
+    a = lambda c, i: lo.off(lo.ct_in + c * lo.Lr + i)
+    b = lambda c, i: lo.off(lo.ct_b + c * lo.Lr + i)
+    for i, j in enumerate(lo.owned_ct):                         # d0 and d2, element-wise
+        out += _setq(lo.moduli[j])
+        out += [f"vle v0, abs+{a(0, i):#x}", f"vle v1, abs+{b(0, i):#x}", "vfqmul.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.rot + i):#x}"]
+        out += [f"vle v0, abs+{a(1, i):#x}", f"vle v1, abs+{b(1, i):#x}", "vfqmul.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.s1 + i):#x}"]
+    for i, j in enumerate(lo.owned_ct):                         # d1 = a0*b1 + a1*b0: a two-term sum in one pass
+        out += _setq(lo.moduli[j])
+        out += [f"vle v0, abs+{a(0, i):#x}", f"vle v1, abs+{b(1, i):#x}", "vfqmul.vv v6, v0, v1",
+                f"vle v0, abs+{a(1, i):#x}", f"vle v1, abs+{b(0, i):#x}", "vfqmul.vv v3, v0, v1", "vfqadd.vv v6, v6, v3",
+                f"vse v6, abs+{lo.off(lo.base1 + i):#x}"]
+    for i, j in enumerate(lo.owned_ct):                         # digits: d2 in coefficient form
+        out += _setq(lo.moduli[j])
+        out += [f"vle v0, abs+{lo.off(lo.s1 + i):#x}", "vintt v2, v0", f"vse v2, abs+{lo.off(lo.dig_slot(j)):#x}"]
+    return out + ["break"]
+
+
 def program_digit_transforms(lo: Layout, jls: Sequence[int]) -> List[str]:
     """Phase 2a for the owned moduli ``jls``: every digit under each of them, NTT form, into SD[jl*L + d]."""
     out = [f"vsetvl {64 * lo.n:#x}"]
@@ -185,8 +217,8 @@ def program_moddown_terms(lo: Layout) -> List[str]:
     return out + ["break"]
 
 
-def program_finish(lo: Layout) -> List[str]:
-    """Phase 4."""
+def program_finish(lo: Layout, add_base1: bool = False) -> List[str]:
+    """Phase 4.  ``add_base1``: the product form, out_1 = BASE1 + r_1 (the rotation has out_1 = r_1)."""
     half = lo.special >> 1
     out = [f"vsetvl {64 * lo.n:#x}"]
     own = list(enumerate(lo.owned_ct))
@@ -212,11 +244,14 @@ def program_finish(lo: Layout) -> List[str]:
         out += _setq(q)
         out += [f"vle v0, abs+{lo.off(lo.s2 + i):#x}", f"vfqmul.vs v2, v0, {pinv:#x}", f"vse v2, abs+{lo.off(lo.s1 + i):#x}"]
         out += [f"vle v0, abs+{lo.off(lo.s2 + lo.Lr + i):#x}", f"vfqmul.vs v2, v0, {pinv:#x}",
-                f"vse v2, abs+{lo.off(lo.out + lo.Lr + i):#x}"]
+                f"vse v2, abs+{lo.off((lo.s1 if add_base1 else lo.out) + lo.Lr + i):#x}"]
     for i, j in own:                                            # c0 += rotated c0
         out += _setq(lo.moduli[j])
         out += [f"vle v0, abs+{lo.off(lo.s1 + i):#x}", f"vle v1, abs+{lo.off(lo.rot + i):#x}", "vfqadd.vv v2, v0, v1",
                 f"vse v2, abs+{lo.off(lo.out + i):#x}"]
+        if add_base1:
+            out += [f"vle v0, abs+{lo.off(lo.s1 + lo.Lr + i):#x}", f"vle v1, abs+{lo.off(lo.base1 + i):#x}",
+                    "vfqadd.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.out + lo.Lr + i):#x}"]
     return out + ["break"]
 
 
@@ -307,7 +342,10 @@ class ShardedKeySwitch:
                         [asm(program_inner(lo, g)) for g in groups(inner_words_per_modulus(lo))]
         self._p_terms = asm(program_moddown_terms(lo)) if lo.L in lo.owned_all else None
         self._p_finish = asm(program_finish(lo))
-        progs = [self._p_digits, self._p_finish] + ([self._p_terms] if self._p_terms is not None else [])
+        self._p_tensor = asm(program_tensor(lo))
+        self._p_finish_mul = asm(program_finish(lo, add_base1=True))
+        progs = [self._p_digits, self._p_finish, self._p_tensor, self._p_finish_mul] + \
+                ([self._p_terms] if self._p_terms is not None else [])
         fixed = sum(len(p) for p in progs)
         inner = sum(len(p) for p in self._p_inner)
         if max([len(p) for p in progs + self._p_inner]) > isa.IRAM_DEPTH:
@@ -316,7 +354,8 @@ class ShardedKeySwitch:
         self._pc = {}
         if self._resident:                                      # everything loaded once
             pc = 0
-            for name, p in [("digits", self._p_digits), ("finish", self._p_finish), ("terms", self._p_terms)] + \
+            for name, p in [("digits", self._p_digits), ("finish", self._p_finish), ("terms", self._p_terms),
+                            ("tensor", self._p_tensor), ("finish_mul", self._p_finish_mul)] + \
                            [(("inner", jl), p) for jl, p in enumerate(self._p_inner)]:
                 if p is None:
                     continue
@@ -341,6 +380,14 @@ class ShardedKeySwitch:
             for i, j in enumerate(lo.owned_ct):
                 self.vp.write(SPM, lo.row(lo.ct_in + c * lo.Lr + i), ct[c, j])
 
+    def load_ct_b(self, ct_full: np.ndarray) -> None:
+        """Second operand of ``multiply`` (same format as ``load_ct``)."""
+        lo = self.lo
+        ct = np.ascontiguousarray(ct_full, dtype=np.uint64).reshape(2, lo.L, lo.n)
+        for c in range(2):
+            for i, j in enumerate(lo.owned_ct):
+                self.vp.write(SPM, lo.row(lo.ct_b + c * lo.Lr + i), ct[c, j])
+
     def read_out(self) -> np.ndarray:
         """Owned result limbs, shape (2, Lr, n)."""
         lo = self.lo
@@ -364,6 +411,19 @@ class ShardedKeySwitch:
         lo = self.lo
         if lo.Lr:
             self._run("digits", self._p_digits, step=k)
+        self._switch("finish", self._p_finish)
+
+    def multiply(self) -> None:
+        """CT_IN * CT_B with relinearisation (the loaded key must be the relinearisation key, i.e.
+        switch from s^2): OUT = (d0 + r_0, d1 + r_1).  No rescale."""
+        lo = self.lo
+        if lo.Lr:
+            self._run("tensor", self._p_tensor)
+        self._switch("finish_mul", self._p_finish_mul)
+
+    def _switch(self, finish_name, finish_words) -> None:
+        """Phases 2-4 on the digits in DIG."""
+        lo = self.lo
         self.ex.all_gather_digits(self.vp, lo)
         for jl, words in enumerate(self._p_inner):
             self._run(("inner", jl), words)
@@ -371,4 +431,4 @@ class ShardedKeySwitch:
             self._run("terms", self._p_terms)
         self.ex.broadcast_terms(self.vp, lo)
         if lo.Lr:
-            self._run("finish", self._p_finish)
+            self._run(finish_name, finish_words)

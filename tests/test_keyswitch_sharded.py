@@ -65,11 +65,59 @@ def test_streamed_program_equals_register_program():
     assert np.array_equal(got, exp)
 
 
+def _toy_case(n=1024, L=3, seed=7):
+    from ckks_toy import ToyCKKS
+    logn = n.bit_length() - 1
+    mods = [oracle.nth_prime(logn, i) for i in range(L)]
+    special = oracle.nth_prime(logn, L)
+    return ToyCKKS(n, mods, special, seed)
+
+
+def _max_err(got, exp):
+    return max(abs(int(a) - int(b)) for a, b in zip(got, exp))
+
+
+def test_rotate_means_automorphism_under_decryption():
+    """What the rotate program MEANS: with a key that switches sigma_k(s) -> s in the reference's
+    key format, decrypt(rotate(ct)) = sigma_k(m) up to key-switch noise.  Exact integers, N = 1024."""
+    toy = _toy_case()
+    n, k = toy.n, pow(3, 5, 2 * toy.n)
+    rng = np.random.default_rng(3)
+    m = [int(x) << 30 for x in rng.integers(-1000, 1000, n)]
+    ct = toy.encrypt(m)
+    ksk = toy.switch_key(toy.automorph(toy.s, k))
+    vp = oracle.OracleVP(spm_rows=8192, ksk_rows=8192)
+    ks = keyswitch.ShardedKeySwitch(vp, n, toy.moduli, toy.special)
+    ks.load_key(ksk); ks.load_ct(ct.reshape(2 * toy.L, n))
+    ks.rotate(k)
+    got = toy.decrypt(ks.read_out())
+    assert _max_err(got, toy.automorph(m, k)) < 1 << 20          # noise << 2^30 message scale
+
+
+def test_multiply_relinearise_means_product_under_decryption():
+    """BASELINE config 4's operation: decrypt(multiply(ct_a, ct_b)) = m_a * m_b (negacyclic) up to noise."""
+    toy = _toy_case(seed=9)
+    n = toy.n
+    rng = np.random.default_rng(4)
+    ma = [int(x) << 20 for x in rng.integers(-100, 100, n)]
+    mb = [int(x) << 20 for x in rng.integers(-100, 100, n)]
+    cta, ctb = toy.encrypt(ma), toy.encrypt(mb)
+    ksk = toy.switch_key(toy.negacyclic(toy.s, toy.s))
+    vp = oracle.OracleVP(spm_rows=8192, ksk_rows=8192)
+    ks = keyswitch.ShardedKeySwitch(vp, n, toy.moduli, toy.special)
+    ks.load_key(ksk); ks.load_ct(cta.reshape(2 * toy.L, n)); ks.load_ct_b(ctb.reshape(2 * toy.L, n))
+    ks.multiply()
+    got = toy.decrypt(ks.read_out())
+    exp = toy.negacyclic(ma, mb)
+    # product scale 2^40 * (sum of 1024 terms up to 10^4): noise from e*m cross terms ~ 2^20 * 100 * 1024 * few
+    assert _max_err(got, exp) < 1 << 36 and max(abs(x) for x in exp) > 1 << 50
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, L, seed, k, out_dir):
+def _worker(rank, world, port, n, L, seed, k, out_dir, op="rotate"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -79,7 +127,11 @@ def _worker(rank, world, port, n, L, seed, k, out_dir):
         ks = keyswitch.ShardedKeySwitch(vp, n, mods, special, world=world, rank=rank,
                                         exchange=keyswitch.Exchange(group=None, tensor_of=None))
         ks.load_key(ksk); ks.load_ct(ct)
-        ks.rotate(k)
+        if op == "multiply":
+            ks.load_ct_b(ct[::-1].copy())
+            ks.multiply()
+        else:
+            ks.rotate(k)
         np.save(os.path.join(out_dir, f"out{rank}.npy"), ks.read_out())
         np.save(os.path.join(out_dir, f"own{rank}.npy"), np.array(ks.lo.owned_ct))
     finally:
@@ -96,6 +148,27 @@ def test_two_rank_sharded_keyswitch_gloo(tmp_path, L):
     exp = _single_rank(oracle.OracleVP(spm_rows=8192, ksk_rows=8192), n, mods, special, ct, ksk, k)
     port = _free_port()
     mp.spawn(_worker, args=(2, port, n, L, seed, k, str(tmp_path)), nprocs=2, join=True)
+    seen = set()
+    for r in range(2):
+        out = np.load(tmp_path / f"out{r}.npy")
+        own = np.load(tmp_path / f"own{r}.npy")
+        for i, j in enumerate(own):
+            assert np.array_equal(out[:, i], exp[:, j]), f"rank {r} limb {j}"
+            seen.add(int(j))
+    assert seen == set(range(L))
+
+
+def test_two_rank_sharded_multiply_gloo(tmp_path):
+    """The ciphertext product + relinearisation, limbs over two ranks: == the single-rank result."""
+    n, L, seed = 1024, 5, 12
+    mods, special, ct, ksk = _random_case(n, L, seed)
+    vp = oracle.OracleVP(spm_rows=8192, ksk_rows=8192)
+    ks = keyswitch.ShardedKeySwitch(vp, n, mods, special)
+    ks.load_key(ksk); ks.load_ct(ct); ks.load_ct_b(ct[::-1].copy())
+    ks.multiply()
+    exp = ks.read_out()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, L, seed, 0, str(tmp_path), "multiply"), nprocs=2, join=True)
     seen = set()
     for r in range(2):
         out = np.load(tmp_path / f"out{r}.npy")
@@ -128,9 +201,16 @@ def test_streamed_keyswitch_on_gpu_n65536():
     lo = keyswitch.Layout(n, mods, special)
     exp = _single_rank(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows), n, mods,
                        special, ct, ksk, k)
+    def product(vp):
+        ks = keyswitch.ShardedKeySwitch(vp, n, mods, special)
+        ks.load_key(ksk); ks.load_ct(ct); ks.load_ct_b(ct[::-1].copy())
+        ks.multiply()
+        return ks.read_out()
+    exp_mul = product(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows))
     with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
         got = _single_rank(vp, n, mods, special, ct, ksk, k)
         assert np.array_equal(got, exp)
+        assert np.array_equal(product(vp), exp_mul)             # ciphertext product + relinearisation (config 4)
         # the RCCL exchange path (zero-copy int64 views of engine memory) with a one-rank group
         os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(_free_port())
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))

@@ -88,13 +88,24 @@ def config45(L):
             vp.write(KSK, jl * L * 2 * lo.rows, rng.integers(0, q, L * 2 * n, dtype=np.uint64))
         ct = np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
         ks.load_ct(ct)
+        ks.load_ct_b(ct[::-1].copy())
         k = pow(3, 5, 2 * n)
         ks.rotate(k); vp.sync()
+        l0 = vp.stats()["kernel_launches"]
         t = timeit(lambda: ks.rotate(k), vp.sync, 5)
-        st = vp.stats()
-        transforms = L + L * (L + 1) + L + 2 * (1 + L)
+        launches_rot = (vp.stats()["kernel_launches"] - l0) / 6
+        ks.multiply(); vp.sync()
+        l0 = vp.stats()["kernel_launches"]
+        tm = timeit(lambda: ks.multiply(), vp.sync, 5)
+        launches_mul = (vp.stats()["kernel_launches"] - l0) / 6
+        transforms = 2 * L + L * (L + 1) + L + 2 * (1 + L)          # rotate: iNTT c0,c1; digits x moduli; NTT rotated c0; mod-down
+        transforms_mul = L + L * (L + 1) + 2 * (1 + L)              # product: iNTT d2; digits x moduli; mod-down
+        # algorithmic bytes of the product: transforms*16N + key 2*L*(L+1)*8N + tensor (4 in, 3 out)*8N*L
+        alg = (transforms_mul * 16 + 2 * L * (L + 1) * 8 + 7 * 8 * L) * n
     return {"L": L, "rotate_keyswitch_ms": t * 1e3, "transforms_per_rotate": transforms,
-            "transform_equiv_per_s": transforms / t, "kernel_launches_total": st["kernel_launches"]}
+            "transform_equiv_per_s": transforms / t, "kernel_launches_per_rotate": launches_rot,
+            "hmult_relin_ms": tm * 1e3, "transforms_per_hmult": transforms_mul, "kernel_launches_per_hmult": launches_mul,
+            "hmult_algorithmic_GBps": alg / tm / 1e9}
 
 
 def aut_batch():
