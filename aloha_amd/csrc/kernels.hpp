@@ -48,7 +48,8 @@ struct AutJob {            // roll == 0: automorphism gather with (k, k_inv); ro
   uint32_t k, k_inv, roll, pad;
 };
 hipError_t ew_batch(hipStream_t st, const EwJob *d_jobs, uint32_t njobs, uint32_t n);
-hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsigned logn);
+// two_pass: every job is an automorphism (no roll) -> two coalesced LDS passes for N >= 2^12 (ew_kernels.hip)
+hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsigned logn, bool two_pass);
 
 // d = init + sum_t a[t] .* b[t]  (mod q), up to kDotTerms terms per launch: the key-switch
 // inner product (keyswitch.mem:46-79) as ONE pass over its operands.

@@ -565,8 +565,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       const void *dj = nullptr;
       s = device_blob(vp, aut_batch.data(), aut_batch.size() * sizeof(aut_batch[0]), &dj);
       if (!s) {
-        hipError_t e = aloha::k::aut_batch(st, (const aloha::k::AutJob *)dj, (uint32_t)aut_batch.size(), batch_logn);
-        vp->stats.kernel_launches++;
+        bool two_pass = !getenv("ALOHA_AUT_GATHER");                    // (the variable is an A/B timing switch)
+        for (const auto &j : aut_batch) two_pass = two_pass && !j.roll;
+        hipError_t e = aloha::k::aut_batch(st, (const aloha::k::AutJob *)dj, (uint32_t)aut_batch.size(), batch_logn, two_pass);
+        vp->stats.kernel_launches += (two_pass && batch_logn >= 12) ? 2 : 1;
         if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "aut_batch: %s", hipGetErrorString(e));
       }
     } else if (pend_kind == PK_EW && !ew_batch.empty()) {

@@ -117,13 +117,17 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, L, seed, k, out_dir, op="rotate"):
+def _worker(rank, world, port, n, L, seed, k, out_dir, op="rotate", engine="oracle"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         mods, special, ct, ksk = _random_case(n, L, seed)
-        vp = oracle.OracleVP(spm_rows=8192, ksk_rows=8192)
+        if engine == "gpu":                                     # both ranks on GPU 0: the exchange still goes through gloo
+            from aloha_amd import vp as avp
+            vp = avp.VP(spm_rows=1 << 15, ksk_rows=1 << 15, max_log_n=16, device=0)
+        else:
+            vp = oracle.OracleVP(spm_rows=8192, ksk_rows=8192)
         ks = keyswitch.ShardedKeySwitch(vp, n, mods, special, world=world, rank=rank,
                                         exchange=keyswitch.Exchange(group=None, tensor_of=None))
         ks.load_key(ksk); ks.load_ct(ct)
@@ -188,6 +192,34 @@ def test_layout_partition_properties():
         assert len(set(slots)) == 24 and max(slots) < world * los[0].Dr
         for lo in los:
             assert lo.spm_rows_needed == lo.slots * 512
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", ["rotate", "multiply"])
+def test_two_rank_sharded_keyswitch_real_engines(tmp_path, op):
+    """Two processes, each with its own engine on the GPU, limbs sharded j mod 2 (uneven: L = 5, P on
+    rank 1), exchanges over gloo: every owned limb equals the single-rank oracle result."""
+    n, L, seed = 4096, 5, 31
+    k = pow(3, 9, 2 * n)
+    mods, special, ct, ksk = _random_case(n, L, seed)
+    vp = oracle.OracleVP(spm_rows=1 << 15, ksk_rows=1 << 15)
+    ks = keyswitch.ShardedKeySwitch(vp, n, mods, special)
+    ks.load_key(ksk); ks.load_ct(ct)
+    if op == "multiply":
+        ks.load_ct_b(ct[::-1].copy()); ks.multiply()
+    else:
+        ks.rotate(k)
+    exp = ks.read_out()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, L, seed, k, str(tmp_path), op, "gpu"), nprocs=2, join=True)
+    seen = set()
+    for r in range(2):
+        out = np.load(tmp_path / f"out{r}.npy")
+        own = np.load(tmp_path / f"own{r}.npy")
+        for i, j in enumerate(own):
+            assert np.array_equal(out[:, i], exp[:, j]), f"rank {r} limb {j}"
+            seen.add(int(j))
+    assert seen == set(range(L))
 
 
 @pytest.mark.gpu
