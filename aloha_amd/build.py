@@ -33,14 +33,20 @@ def _newest(paths) -> float:
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build_ablation(level: int) -> str:
-    """Timing-experiment variant of the library (ALOHA_ABLATE=level); results are invalid."""
-    out = os.path.join(LIBDIR, f"libaloha_vp_ablate{level}.so")
+def build_variant(name: str, defines) -> str:
+    """A/B variant of the library with extra -D macros -> lib/libaloha_vp_<name>.so (select it with
+    ALOHA_VP_LIB=...; bench.py then skips its oracle guard, variants may compute garbage on purpose)."""
+    out = os.path.join(LIBDIR, f"libaloha_vp_{name}.so")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", f"-DALOHA_ABLATE={level}",
-           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl,-rpath,/opt/rocm/lib"]
+    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}"] + [f"-D{d}" for d in defines] + \
+          ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return out
+
+
+def build_ablation(level: int) -> str:
+    """Timing-experiment variant of the library (ALOHA_ABLATE=level); results are invalid."""
+    return build_variant(f"ablate{level}", [f"ALOHA_ABLATE={level}"])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -71,3 +77,6 @@ if __name__ == "__main__":
     for a in sys.argv[1:]:
         if a.startswith("--ablate="):
             print(build_ablation(int(a.split("=")[1])))
+        if a.startswith("--variant="):                      # --variant=name:MACRO=1,MACRO2=0
+            name, defs = a.split("=", 1)[1].split(":", 1)
+            print(build_variant(name, defs.split(",")))

@@ -25,16 +25,30 @@ ALOHA_DEV u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 // LLVM's InstCombine re-merges the 32-bit limb algebra below into generic 64-bit multiplies
 // and the hand-counted issue budget is lost.  The asm statements have only VGPR/SGPR
 // operands and no memory side effects, so the scheduler is free to move, CSE or delete them.
-// v_mad_u64_u32 also writes a carry-out SGPR pair (VOP3B); it is a dead dummy output here.
+// v_mad_u64_u32 also writes a carry-out SGPR pair (VOP3B): always the fixed pair s[94:95], which
+// nothing reads -- a compiler-allocated dummy can land on an SGPR that a later VALU instruction
+// reads, and the hazard recogniser then pads every such pair with s_nop.
 // "_s" variants take the second factor from an SGPR (wave-uniform twiddle / modulus limbs).
 ALOHA_DEV u64 mad32(u32 a, u32 b, u64 c) {
-  u64 r, cy;
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+  u64 r;
+  asm("v_mad_u64_u32 %0, s[94:95], %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "s94", "s95");
   return r;
 }
 ALOHA_DEV u64 mad32_s(u32 a, u32 b, u64 c) {
-  u64 r, cy;
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cy) : "v"(a), "s"(b), "v"(c));
+  u64 r;
+  asm("v_mad_u64_u32 %0, s[94:95], %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c) : "s94", "s95");
+  return r;
+}
+// a*b with a zero addend (inline constant): the low dword is mullo, but the result can head a
+// 64-bit accumulator chain without a zero-extension move
+ALOHA_DEV u64 mad32_z(u32 a, u32 b) {
+  u64 r;
+  asm("v_mad_u64_u32 %0, s[94:95], %1, %2, 0" : "=v"(r) : "v"(a), "v"(b) : "s94", "s95");
+  return r;
+}
+ALOHA_DEV u64 mad32_zs(u32 a, u32 b) {
+  u64 r;
+  asm("v_mad_u64_u32 %0, s[94:95], %1, %2, 0" : "=v"(r) : "v"(a), "s"(b) : "s94", "s95");
   return r;
 }
 ALOHA_DEV u32 mullo32(u32 a, u32 b) {
@@ -129,10 +143,54 @@ ALOHA_DEV u64 shoup_qhat_exact(u64 a, u64 wp) {
 }
 
 // out0 = X + (a*w + qhat*nq)  (mod 2^64): the X + T sum rides on the accumulator chain.
+// Every VALU instruction of this family costs one ~4-cycle issue slot on gfx950 whatever it
+// computes (tools/ubench_valu.hip), so the cross terms -- of which only the low dword matters --
+// ride a multiply-add chain of their own whose high dword is garbage: 4 instructions instead of
+// 4 multiplies + 2 three-input adds + a register move.
+#ifndef ALOHA_FOLD_CHAIN
+#define ALOHA_FOLD_CHAIN 1
+#endif
 template <bool UNI>
 ALOHA_DEV u64 shoup_fold_add(u64 X, u64 a, u64 w, u64 qhat, u64 nq) {
   u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(w), w1 = hi32(w);
   u32 b0 = lo32(qhat), b1 = hi32(qhat), n0 = lo32(nq), n1 = hi32(nq);
+#if ALOHA_FOLD_CHAIN == 2
+  // the six multiply-adds as ONE statement (no inter-statement padding), the two chains interleaved
+  u64 t, acc;
+  if (UNI)
+    asm("v_mad_u64_u32 %0, s[94:95], %3, %5, 0\n\t"
+        "v_mad_u64_u32 %1, s[94:95], %2, %4, %10\n\t"
+        "v_mad_u64_u32 %0, s[94:95], %2, %5, %0\n\t"
+        "v_mad_u64_u32 %1, s[94:95], %6, %8, %1\n\t"
+        "v_mad_u64_u32 %0, s[94:95], %7, %8, %0\n\t"
+        "v_mad_u64_u32 %0, s[94:95], %6, %9, %0"
+        : "=&v"(t), "=&v"(acc)
+        : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(b0), "v"(b1), "s"(n0), "s"(n1), "v"(X)
+        : "s94", "s95");
+  else
+    asm("v_mad_u64_u32 %0, s[94:95], %3, %5, 0\n\t"
+        "v_mad_u64_u32 %1, s[94:95], %2, %4, %10\n\t"
+        "v_mad_u64_u32 %0, s[94:95], %2, %5, %0\n\t"
+        "v_mad_u64_u32 %1, s[94:95], %6, %8, %1\n\t"
+        "v_mad_u64_u32 %0, s[94:95], %7, %8, %0\n\t"
+        "v_mad_u64_u32 %0, s[94:95], %6, %9, %0"
+        : "=&v"(t), "=&v"(acc)
+        : "v"(a0), "v"(a1), "v"(w0), "v"(w1), "v"(b0), "v"(b1), "s"(n0), "s"(n1), "v"(X)
+        : "s94", "s95");
+  u32 h = hi32(acc);
+  asm("v_add_u32 %0, %0, %1" : "+v"(h) : "v"(lo32(t)));
+  return pack64(lo32(acc), h);
+#elif ALOHA_FOLD_CHAIN
+  u64 t = UNI ? mad32_zs(a1, w0) : mad32_z(a1, w0);
+  t = UNI ? mad32_s(a0, w1, t) : mad32(a0, w1, t);
+  t = mad32_s(b1, n0, t);
+  t = mad32_s(b0, n1, t);                                       // lo32(t) = sum of the four cross terms (mod 2^32)
+  u64 acc = UNI ? mad32_s(a0, w0, X) : mad32(a0, w0, X);
+  acc = mad32_s(b0, n0, acc);
+  u32 h = hi32(acc);
+  asm("v_add_u32 %0, %0, %1" : "+v"(h) : "v"(lo32(t)));          // pinned: as C, LLVM widens this to a 64-bit add plus moves
+  return pack64(lo32(acc), h);
+#else
   u32 x0 = UNI ? mullo32_s(a1, w0) : mullo32(a1, w0);
   u32 x1 = UNI ? mullo32_s(a0, w1) : mullo32(a0, w1);
   u32 x2 = mullo32_s(b1, n0);
@@ -140,6 +198,7 @@ ALOHA_DEV u64 shoup_fold_add(u64 X, u64 a, u64 w, u64 qhat, u64 nq) {
   u32 hi = hi32(X) + x0 + x1 + x2 + x3;
   u64 acc = UNI ? mad32_s(a0, w0, pack64(lo32(X), hi)) : mad32(a0, w0, pack64(lo32(X), hi));
   return mad32_s(b0, n0, acc);
+#endif
 }
 
 template <bool UNI, bool EXACT>

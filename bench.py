@@ -35,13 +35,14 @@ import torch  # noqa: E402
 LOGN = 16
 N = 1 << LOGN
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_SUMMARY = "r01_k_pmc_summary.json"   # written by tools/collect_pmc.sh for the kernels of this commit
 
 
 def measured_traffic_per_step(limbs: int):
     """HBM bytes per step from the committed rocprofv3 PMC summary (FETCH_SIZE x2 per the guide's
     gfx950 correction + WRITE_SIZE, separate --pmc passes of this same command), scaled to the
     batch size; None when no summary is present."""
-    path = os.path.join(ROOT, "profiles", "r01_b_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
     try:
         with open(path) as f:
             d = json.load(f)["derived"]
@@ -173,7 +174,7 @@ def main() -> int:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_per_step(B),
                          "note": "achieved = 16*N*B algorithmic bytes / device time of one step (both "
                                  "tile kernels, HIP events on the engine's stream); traffic = HBM bytes "
-                                 "per step from profiles/r01_b_pmc_summary.json (two passes => 2.04x "
+                                 f"per step from profiles/{PMC_SUMMARY} (two passes + twiddle blocks => 2.14x "
                                  "algorithmic); see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
