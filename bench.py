@@ -5,8 +5,9 @@
 
 One "step" = one pass of the hot path (vntt, fused over the batch: aloha_vp_ntt_rows) over a
 batch of L x P limbs of N = 2^16 coefficients resident in HBM, in place.  The default batch
-(32 primes x 32 limbs = 1024 limbs = 512 MiB) is twice the 256 MiB Infinity Cache, so every
-step streams from HBM.  For N > 1 the driver launches one rank per GPU (torch.distributed,
+(32 primes x 128 limbs = 4096 limbs = 2 GiB) is eight times the 256 MiB Infinity Cache, so every
+step streams from HBM, and long enough (1.6 ms) that the launch tails of the two kernels are
+under 2 % (1024 limbs: 2.40 M NTT/s, 4096: 2.53 M; SURVEY 8d asks for "B >= 256, report B").  For N > 1 the driver launches one rank per GPU (torch.distributed,
 backend nccl = RCCL); limbs are independent so ranks share nothing on the data path (weak
 scaling: every rank transforms its own batch), only the barrier and the max-over-ranks of the
 elapsed time go through the collective.
@@ -35,7 +36,7 @@ import torch  # noqa: E402
 LOGN = 16
 N = 1 << LOGN
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = "r01_k_pmc_summary.json"   # written by tools/collect_pmc.sh for the kernels of this commit
+PMC_SUMMARY = "r01_l_pmc_summary.json"   # written by tools/collect_pmc.sh for the kernels of this commit
 
 
 def measured_traffic_per_step(limbs: int):
@@ -74,7 +75,7 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--primes", type=int, default=32)
-    ap.add_argument("--polys", type=int, default=32)
+    ap.add_argument("--polys", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inverse", action="store_true", help="time vintt instead (side metric; headline is forward)")
     args = ap.parse_args()
@@ -111,20 +112,34 @@ def main() -> int:
                 stream=stream.cuda_stream)
     primes = [avp.nth_prime(LOGN, i) for i in range(L)]
     moduli = [q for q in primes for _ in range(P)]
-    rng = np.random.default_rng(0xA10A + rank)
-    for i, q in enumerate(primes):                          # synthetic canonical residues, prime by prime
-        blk = rng.integers(0, q, size=P * N, dtype=np.uint64)
-        vp.write(avp.SPM, i * P * rows_per_limb, blk)
-        if i == 0:
-            first_in = blk[:N].copy()
+    # synthetic canonical residues, uniform in [0, q), generated on the device straight into the
+    # engine's memory (a zero-copy int64 view), prime by prime
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0xA10A + rank)
+    for i, q in enumerate(primes):
+        class _View:
+            __cuda_array_interface__ = {"shape": (P * N,), "typestr": "<i8", "version": 2,
+                                        "data": (vp.device_ptr(avp.SPM, i * P * rows_per_limb), False)}
+        torch.as_tensor(_View(), device="cuda").random_(0, q, generator=gen)
+    torch.cuda.synchronize()
+    first_in = vp.read(avp.SPM, 0, N)
+    assert int(first_in.max()) < primes[0]
     # correctness guard inside the bench: the first limb of the first step against the oracle
     vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli)
     vp.sync()
     if rank == 0 and not os.environ.get("ALOHA_VP_LIB"):   # (ablation builds compute garbage on purpose)
         import oracle
         got = vp.read(avp.SPM, 0, N)
+        last = (B - 1) * rows_per_limb
         if not np.array_equal(got, oracle.ntt(first_in, primes[0])):
             print("bench.py: GPU result differs from the oracle", file=sys.stderr)
+            return 3
+        # ... and the last limb of the batch by round trip through the inverse transform
+        before = vp.read(avp.SPM, last, N)
+        vp.ntt_rows(avp.SPM, last, last, LOGN, [primes[-1]], inverse=True)
+        vp.ntt_rows(avp.SPM, last, last, LOGN, [primes[-1]])
+        if not np.array_equal(vp.read(avp.SPM, last, N), before):
+            print("bench.py: NTT round trip failed on the last limb", file=sys.stderr)
             return 3
     inv = bool(args.inverse)
     for _ in range(max(0, args.warmup - 1)):
@@ -174,8 +189,8 @@ def main() -> int:
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_per_step(B),
                          "note": "achieved = 16*N*B algorithmic bytes / device time of one step (both "
                                  "tile kernels, HIP events on the engine's stream); traffic = HBM bytes "
-                                 f"per step from profiles/{PMC_SUMMARY} (two passes + twiddle blocks => 2.14x "
-                                 "algorithmic); see DESIGN.md"},
+                                 f"per step from profiles/{PMC_SUMMARY} (rocprofv3 --pmc, FETCH_SIZE x2 + "
+                                 "WRITE_SIZE; two passes + twiddle blocks => ~2.04x algorithmic); see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
