@@ -60,6 +60,15 @@ __global__ __launch_bounds__(256) void vaut_kernel(u64 *__restrict__ out, const 
   }
 }
 
+__global__ __launch_bounds__(256) void vautn_kernel(u64 *__restrict__ out, const u64 *__restrict__ in, uint32_t n,
+                                                    uint32_t kk) {
+  const unsigned sh = __clz(n) + 1;
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+    const uint32_t e = ((2 * (__brev(j) >> sh) + 1) * kk) & (2 * n - 1);
+    out[j] = in[__brev((e - 1) >> 1) >> sh];
+  }
+}
+
 __global__ __launch_bounds__(256) void vroli_kernel(u64 *__restrict__ out, const u64 *__restrict__ in,
                                                     uint32_t n, uint32_t s) {
   for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256)
@@ -95,8 +104,12 @@ __global__ __launch_bounds__(256) void ew_batch_kernel(const EwJob *__restrict__
 __global__ __launch_bounds__(256) void aut_batch_kernel(const AutJob *__restrict__ jobs, uint32_t n) {
   const AutJob jb = jobs[blockIdx.y];
   for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
-    if (jb.roll) {
+    if (jb.roll == 1) {
       jb.out[j] = jb.in[(j + jb.k) & (n - 1)];
+    } else if (jb.roll == 2) {                             // vautn: out[j] = in[brv(((2 brv(j) + 1) k mod 2N - 1) / 2)]
+      const unsigned sh = __clz(n) + 1;                    // 32 - log2 N
+      const uint32_t e = ((2 * (__brev(j) >> sh) + 1) * jb.k) & (2 * n - 1);
+      jb.out[j] = jb.in[__brev((e - 1) >> 1) >> sh];
     } else {
       const uint32_t i = (j * jb.k_inv) & (n - 1);
       const uint32_t t = (i * jb.k) & (2 * n - 1);
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(256) void dot_kernel(DotArgs g, uint32_t n2) {
     }
     for (int t = 0; t < g.nterms; t++) {
       const u64x2 va = reinterpret_cast<const u64x2 *>(g.a[t])[i];
-      const u64x2 vb = reinterpret_cast<const u64x2 *>(g.b[t])[i];
+      const u64x2 vb = g.b[t] ? reinterpret_cast<const u64x2 *>(g.b[t])[i] : u64x2{g.s[t], g.s[t]};   // (s is normalised)
       acc.x = addmod(acc.x, mulmod_barrett(csub(va.x, q), csub(vb.x, q), q, mu), q);
       acc.y = addmod(acc.y, mulmod_barrett(csub(va.y, q), csub(vb.y, q), q, mu), q);
     }
@@ -185,17 +198,20 @@ __global__ __launch_bounds__(256) void dot_batch_kernel(const DotArgs *__restric
       acc = reinterpret_cast<const u64x2 *>(g->init)[i];
       acc.x = csub(acc.x, q); acc.y = csub(acc.y, q);
     }
+    auto second = [&](int t) -> u64x2 {                      // vector operand, or the scalar of a vfqmul.vs term (uniform branch)
+      return g->b[t] ? reinterpret_cast<const u64x2 *>(g->b[t])[i] : u64x2{g->s[t], g->s[t]};
+    };
     int t = 0;
     for (; t + 1 < nterms; t += 2) {                         // two terms per trip: four 16-byte loads in flight
-      const u64x2 a0 = reinterpret_cast<const u64x2 *>(g->a[t])[i], b0 = reinterpret_cast<const u64x2 *>(g->b[t])[i];
-      const u64x2 a1 = reinterpret_cast<const u64x2 *>(g->a[t + 1])[i], b1 = reinterpret_cast<const u64x2 *>(g->b[t + 1])[i];
+      const u64x2 a0 = reinterpret_cast<const u64x2 *>(g->a[t])[i], b0 = second(t);
+      const u64x2 a1 = reinterpret_cast<const u64x2 *>(g->a[t + 1])[i], b1 = second(t + 1);
       acc.x = addmod(acc.x, mulmod_barrett(csub(a0.x, q), csub(b0.x, q), q, mu), q);
       acc.y = addmod(acc.y, mulmod_barrett(csub(a0.y, q), csub(b0.y, q), q, mu), q);
       acc.x = addmod(acc.x, mulmod_barrett(csub(a1.x, q), csub(b1.x, q), q, mu), q);
       acc.y = addmod(acc.y, mulmod_barrett(csub(a1.y, q), csub(b1.y, q), q, mu), q);
     }
     if (t < nterms) {
-      const u64x2 a0 = reinterpret_cast<const u64x2 *>(g->a[t])[i], b0 = reinterpret_cast<const u64x2 *>(g->b[t])[i];
+      const u64x2 a0 = reinterpret_cast<const u64x2 *>(g->a[t])[i], b0 = second(t);
       acc.x = addmod(acc.x, mulmod_barrett(csub(a0.x, q), csub(b0.x, q), q, mu), q);
       acc.y = addmod(acc.y, mulmod_barrett(csub(a0.y, q), csub(b0.y, q), q, mu), q);
     }
@@ -275,6 +291,12 @@ hipError_t vaut(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 q, u
   const uint32_t n = 1u << logn;
   hipLaunchKernelGGL(vaut_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, in, n, q, (uint32_t)kk,
                      (uint32_t)kinv);
+  return hipGetLastError();
+}
+
+hipError_t vautn(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 kk) {
+  const uint32_t n = 1u << logn;
+  hipLaunchKernelGGL(vautn_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, in, n, (uint32_t)kk);
   return hipGetLastError();
 }
 

@@ -30,6 +30,8 @@ hipError_t ew(hipStream_t st, EwOp op, u64 *d, const u64 *a, const u64 *b, u64 s
 // automorphism gather: out[j] = +-in[j * k_inv mod N], sign from (i*k mod 2N) >= N
 // (src/vp/vxu/vxu_lane.sv:594-598); k already reduced mod N, k_inv = k^-1 mod N
 hipError_t vaut(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 q, u64 k, u64 k_inv);
+// extension: the same automorphism on an NTT-form limb -- out[j] = in[brv(((2 brv(j)+1) k mod 2N - 1)/2)], k mod N
+hipError_t vautn(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 k);
 // cyclic roll: out[j] = in[(j + s) mod N]  (vxu_lane.sv:595,:597)
 hipError_t vroli(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 s);
 
@@ -41,7 +43,7 @@ struct EwJob {             // d = op(a, b | s) on n words under modulus m
   ModCtx m;
   int op, pad;
 };
-struct AutJob {            // roll == 0: automorphism gather with (k, k_inv); roll == 1: cyclic roll by k
+struct AutJob {            // roll == 0: automorphism gather with (k, k_inv); 1: cyclic roll by k; 2: vautn (NTT-form permutation by k)
   u64 *out;
   const u64 *in;
   u64 q;
@@ -51,12 +53,13 @@ hipError_t ew_batch(hipStream_t st, const EwJob *d_jobs, uint32_t njobs, uint32_
 // two_pass: every job is an automorphism (no roll) -> two coalesced LDS passes for N >= 2^12 (ew_kernels.hip)
 hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsigned logn, bool two_pass);
 
-// d = init + sum_t a[t] .* b[t]  (mod q), up to kDotTerms terms per launch: the key-switch
+// d = init + sum_t a[t] .* (b[t] | s[t])  (mod q), up to kDotTerms terms per launch: the key-switch
 // inner product (keyswitch.mem:46-79) as ONE pass over its operands.
 constexpr int kDotTerms = 64;
 struct DotArgs {
   const u64 *a[kDotTerms];
-  const u64 *b[kDotTerms];
+  const u64 *b[kDotTerms];   // nullptr: term t is a[t] times the scalar s[t] (vfqmul.vs)
+  u64 s[kDotTerms];
   const u64 *init;         // may be null
   u64 *d;
   ModCtx m;

@@ -477,14 +477,14 @@ bool reads_reg(const Decoded &d, unsigned r) {
       if (d.funct3 == 1) return d.vs1 == r;
       if (d.funct3 == 2) return d.vs2 == r;
       return false;
-    case 0x0d: case 0x11: case 0x15: case 0x19: case 0x02: case 0x06: case 0x07: return d.vs1 == r;
+    case 0x0d: case 0x11: case 0x15: case 0x19: case 0x1d: case 0x02: case 0x06: case 0x07: return d.vs1 == r;
     default: return false;
   }
 }
 
 bool writes_reg(const Decoded &d, unsigned r) {
   switch (d.funct6) {
-    case 0x01: case 0x05: case 0x09: case 0x0d: case 0x11: case 0x15: case 0x19: case 0x02: case 0x06: case 0x03:
+    case 0x01: case 0x05: case 0x09: case 0x0d: case 0x11: case 0x15: case 0x19: case 0x1d: case 0x02: case 0x06: case 0x03:
       return d.vd == r;
     default: return false;
   }
@@ -553,7 +553,9 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   unsigned batch_logn = 0;
   // Lazy dot products: register r stands for sum_t a_t .* b_t (mod lazy_q[r]) over memory
   // operands -- the key-switch inner product (keyswitch.mem:46-79) evaluated in one pass.
-  std::vector<std::pair<const u64 *, const u64 *>> lazy[ALOHA_NVREG];
+  // (second == nullptr: the term is a_t times the scalar s, from vfqmul.vs)
+  struct LazyTerm { const u64 *first, *second; u64 s; };
+  std::vector<LazyTerm> lazy[ALOHA_NVREG];
   uint64_t lazy_q[ALOHA_NVREG] = {0};
 
   auto rd = [&](unsigned r) -> const u64 * { return alias[r] ? alias[r] : vreg(vp, r); };
@@ -619,7 +621,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     for (size_t t0 = 0; t0 < lazy[r].size(); t0 += aloha::k::kDotTerms) {
       aloha::k::DotArgs g{};
       g.nterms = (int)std::min<size_t>(aloha::k::kDotTerms, lazy[r].size() - t0);
-      for (int t = 0; t < g.nterms; t++) { g.a[t] = lazy[r][t0 + t].first; g.b[t] = lazy[r][t0 + t].second; }
+      for (int t = 0; t < g.nterms; t++) { g.a[t] = lazy[r][t0 + t].first; g.b[t] = lazy[r][t0 + t].second; g.s[t] = lazy[r][t0 + t].s; }
       g.init = init; g.d = dst; g.m = modctx(lazy_q[r]);
       HIPCK(vp, aloha::k::dot(st, g, n));
       vp->stats.kernel_launches++;
@@ -633,7 +635,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   auto before_mem_write = [&](const u64 *dst, size_t n, uint32_t next_pc) -> aloha_status {
     for (unsigned r = 0; r < ALOHA_NVREG; r++) {
       for (const auto &t : lazy[r])
-        if (overlap(t.first, dst, n) || overlap(t.second, dst, n)) {
+        if (overlap(t.first, dst, n) || (t.second && overlap(t.second, dst, n))) {
           if (dead_from(vp, next_pc, r)) lazy[r].clear();
           else { aloha_status s = materialise(r, nullptr, (uint32_t)n); if (s) return s; }
           break;
@@ -665,7 +667,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       aloha_status s = vl_logn(vp->vl_bits, vp->max_logn, &logn);
       if (s) ALOHA_RUN_FAIL(s, "pc %u: VL = %llu bits", pc, (u64)vp->vl_bits);
       n = 1u << logn;
-      if (funct6 != 0x03 && funct6 != 0x07 && funct6 != 0x19 && !(q > (1ull << 59) && q < (1ull << 60)))
+      if (funct6 != 0x03 && funct6 != 0x07 && funct6 != 0x19 && funct6 != 0x1d && !(q > (1ull << 59) && q < (1ull << 60)))
         ALOHA_RUN_FAIL(ALOHA_ERR_MODULUS, "pc %u: arithmetic with q = %#llx", pc, (u64)q);
     }
     // a following `vse vd, Z` this instruction may write to directly
@@ -749,9 +751,16 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         ALOHA_RUN_CK(direct_store(&z));
         // element-wise in place (z == a or z == b) is safe; a partial overlap is not
         if (z && ((a != z && overlap(a, z, n)) || (b && b != z && overlap(b, z, n)))) z = nullptr;
+        if (fuse && !z && op == aloha::k::EW_MUL_VS && alias[ra]) {
+          // memory operand times a scalar kept in a register: a lazy term as well (base-conversion sums)
+          lazy[vd].assign(1, LazyTerm{a, nullptr, s});
+          lazy_q[vd] = q;
+          alias[vd] = nullptr;
+          break;
+        }
         if (fuse && !z && op == aloha::k::EW_MUL_VV && alias[ra] && alias[rb]) {
           // product of two memory operands kept in a register: start a lazy dot product
-          lazy[vd].assign(1, std::make_pair(a, b));
+          lazy[vd].assign(1, LazyTerm{a, b, 0});
           lazy_q[vd] = q;
           alias[vd] = nullptr;
           break;
@@ -778,10 +787,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         alias[vd] = nullptr;
         break;
       }
-      case 0x15: case 0x19: {                                      // vaut / vroli  :460-501,:549-558
+      case 0x15: case 0x19: case 0x1d: {                           // vaut / vroli  :460-501,:549-558; vautn (0x1d): extension, NTT-form
         const uint64_t k = (step + imm) & (n - 1);                 // scalar_iconn = csr_step + imm, kept mod N
                                                                    // (vxu_lane.sv:594, vxu_top_tb.sv:603)
-        if (funct6 == 0x15 && !((step + imm) & 1))
+        if (funct6 != 0x19 && !((step + imm) & 1))
           ALOHA_RUN_FAIL(ALOHA_ERR_AUT, "pc %u: vaut with even exponent %llu", pc, (u64)(step + imm));
         const u64 *in = rd(vs1);
         u64 *z = nullptr;
@@ -794,7 +803,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
           if (!can_join(PK_AUT, logn, in, nullptr, z, n)) ALOHA_RUN_CK(flush());
           aloha::k::AutJob jb{};
-          jb.out = z; jb.in = in; jb.q = q; jb.k = (uint32_t)k; jb.roll = funct6 == 0x19;
+          jb.out = z; jb.in = in; jb.q = q; jb.k = (uint32_t)k; jb.roll = funct6 == 0x19 ? 1 : funct6 == 0x1d ? 2 : 0;
           if (!jb.roll) {
             uint64_t kinv = 1;                                     // k^-1 mod N by Newton iteration (k odd)
             for (int it = 0; it < 5; it++) kinv = kinv * (2 - k * kinv);
@@ -816,6 +825,8 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           for (int it = 0; it < 5; it++) kinv = kinv * (2 - k * kinv);
           kinv &= (n - 1);
           HIPCK(vp, aloha::k::vaut(st, out, in, logn, q, k, kinv));
+        } else if (funct6 == 0x1d) {
+          HIPCK(vp, aloha::k::vautn(st, out, in, logn, k));
         } else {
           HIPCK(vp, aloha::k::vroli(st, out, in, logn, k));
         }
@@ -870,9 +881,9 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         if (!p) ALOHA_RUN_FAIL(ALOHA_ERR_ADDR, "pc %u: vse imm %#llx out of range", pc, (u64)imm);
         if (!lazy[vs1].empty()) {                                  // (only reached when vs1 is dead afterwards)
           bool clash = false;                                      // the sum must not read what it overwrites
-          for (const auto &t : lazy[vs1]) clash |= overlap(t.first, p, n) || overlap(t.second, p, n);
+          for (const auto &t : lazy[vs1]) clash |= overlap(t.first, p, n) || (t.second && overlap(t.second, p, n));
           if (!clash) {
-            std::vector<std::pair<const u64 *, const u64 *>> terms;
+            std::vector<LazyTerm> terms;
             terms.swap(lazy[vs1]);                                 // keep before_mem_write from evaluating it twice
             ALOHA_RUN_CK(before_mem_write(p, n, pc + 1));
             lazy[vs1].swap(terms);
@@ -885,21 +896,21 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
                 if (pend_kind != PK_DOT || batch_logn != logn) return false;
                 bool clear = !hits(p, n, dot_w_lo, dot_w_hi) && !hits(p, n, dot_a_lo, dot_a_hi) && !hits(p, n, dot_b_lo, dot_b_hi);
                 for (const auto &t : lazy[vs1])
-                  clear = clear && !hits(t.first, n, dot_w_lo, dot_w_hi) && !hits(t.second, n, dot_w_lo, dot_w_hi);
+                  clear = clear && !hits(t.first, n, dot_w_lo, dot_w_hi) && !hits(t.second, n, dot_w_lo, dot_w_hi);   // (hits(nullptr) is false)
                 if (clear) return true;
                 for (const auto &g : dot_batch) {
                   if (overlap(p, g.d, n)) return false;
                   for (int t = 0; t < g.nterms; t++)
-                    if (overlap(p, g.a[t], n) || overlap(p, g.b[t], n)) return false;
+                    if (overlap(p, g.a[t], n) || (g.b[t] && overlap(p, g.b[t], n))) return false;
                   for (const auto &t : lazy[vs1])
-                    if (overlap(t.first, g.d, n) || overlap(t.second, g.d, n)) return false;
+                    if (overlap(t.first, g.d, n) || (t.second && overlap(t.second, g.d, n))) return false;
                 }
                 return true;
               };
               if (!joinable()) ALOHA_RUN_CK(flush());
               aloha::k::DotArgs g{};
               g.nterms = (int)lazy[vs1].size();
-              for (int t = 0; t < g.nterms; t++) { g.a[t] = lazy[vs1][t].first; g.b[t] = lazy[vs1][t].second; }
+              for (int t = 0; t < g.nterms; t++) { g.a[t] = lazy[vs1][t].first; g.b[t] = lazy[vs1][t].second; g.s[t] = lazy[vs1][t].s; }
               g.init = nullptr; g.d = p; g.m = modctx(lazy_q[vs1]);
               dot_batch.push_back(g);
               auto grow = [&](const u64 *x, const u64 *&lo, const u64 *&hi) {
@@ -907,7 +918,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
                 if (!hi || x + n > hi) hi = x + n;
               };
               grow(p, dot_w_lo, dot_w_hi);
-              for (int t = 0; t < g.nterms; t++) { grow(g.a[t], dot_a_lo, dot_a_hi); grow(g.b[t], dot_b_lo, dot_b_hi); }
+              for (int t = 0; t < g.nterms; t++) { grow(g.a[t], dot_a_lo, dot_a_hi); if (g.b[t]) grow(g.b[t], dot_b_lo, dot_b_hi); }
               pend_kind = PK_DOT; batch_logn = logn;
               lazy[vs1].clear();
               break;

@@ -1,0 +1,360 @@
+"""Hybrid key-switch with several primes per digit and NTT-domain automorphism,
+limb-sharded over ranks like ``keyswitch.py``.
+
+The reference's program (``keyswitch.mem:1-122``) uses one digit per ciphertext prime and one
+special prime: L*(L+1) digit transforms and a key of 2*L*(L+1) limbs per switch.  Grouping
+``alpha`` primes into a digit (dnum = ceil(L/alpha) digits, K special primes, P = prod p_k) cuts
+both to dnum*(L+K); applying the automorphism to the NTT-form limbs (the ``vautn`` extension)
+removes the iNTT -> vaut -> NTT detour of the rotated c0.  With alpha = 1, K = 1 the arithmetic
+below is the reference's own, step for step, and reproduces its golden rotate bit-exactly
+(tests) -- which is what pins this generalisation; for alpha > 1 no reference vectors exist and
+parity is against the oracle's ISA machine plus decryption semantics (tests/ckks_toy.py).
+
+    digits       D_d = {q_i : i in [d*alpha, (d+1)*alpha)},   Q_d = prod D_d
+    phase 1      X[i]  = the NTT-form limb to switch (vautn(c1[i]) or d2[i]);  ROT[i] = vautn(c0[i]) or d0[i]
+                 Y[i]  = iNTT(X[i]) * (Q_d/q_i)^-1  mod q_i                          (coefficient form)
+    exchange     ALL-GATHER of Y[0..L-1]
+    phase 2a     ModUp: for every owned modulus m_j (q's and p's) and digit d with m_j not in D_d
+                     SD[j][d] = NTT_j( sum_{i in D_d} Y[i] * (Q_d/q_i mod m_j)  mod m_j )
+                 (for m_j in D_d the digit's limb under m_j is X[j] itself)
+    phase 2b     acc_c[j] = sum_d SD[j][d] * KEY[j][d][c]
+    phase 3      owners of p_k:  W[k][c] = (iNTT(acc_c[p_k]) + floor(P/2)) * (P/p_k)^-1  mod p_k
+    exchange     ALL-GATHER of W (2K limbs)
+    phase 4      t_c[j] = NTT_j( sum_k W[k][c] * (P/p_k mod q_j) - floor(P/2) );
+                 r_c[j] = (acc_c[j] - t_c[j]) * P^-1 mod q_j;   out = (ROT + r_0, [BASE1 +] r_1)
+
+Everything is HE-ISA: the ModUp / ModDown sums are ``vfqmul.vs`` / ``vfqadd.vv`` chains over memory
+operands, which the engine's fusing sequencer evaluates as one pass per output limb and one
+launch per program (scalar lazy terms), exactly like the digit-by-key products.  The basis
+conversions are the usual fast (approximate) ones: the lifted digit may exceed the true value by
+a small multiple of Q_d, which the key's structure cancels mod Q.
+
+Key layout: limb ((jl*dnum + d)*2 + c) for owned modulus jl, digit d, component c -- the
+reference's [modulus][digit][component] order (keyswitch.mem:46-77) with dnum digits.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import isa
+from .keyswitch import Exchange, LANES, SPM, KSK, _setq, owner
+
+
+def _prod(xs):
+    p = 1
+    for x in xs:
+        p *= int(x)
+    return p
+
+
+class HybridLayout:
+    def __init__(self, n: int, moduli: Sequence[int], specials: Sequence[int], alpha: int, world: int = 1,
+                 rank: int = 0, base_row: int = 0):
+        self.n, self.moduli, self.specials, self.alpha = n, [int(q) for q in moduli], [int(p) for p in specials], alpha
+        self.world, self.rank, self.base_row = world, rank, base_row
+        self.L, self.K = len(self.moduli), len(self.specials)
+        self.mods_all = self.moduli + self.specials
+        self.dnum = -(-self.L // alpha)
+        self.rows = n // LANES
+        self.owned_ct = [j for j in range(self.L) if owner(j, world) == rank]
+        self.owned_all = [j for j in range(self.L + self.K) if owner(j, world) == rank]
+        self.owned_sp = [k for k in range(self.K) if owner(self.L + k, world) == rank]
+        self.Lr, self.Mr = len(self.owned_ct), len(self.owned_all)
+        self.Yr = -(-self.L // world)
+        self.Wr = 2 * max(1, max(sum(1 for k in range(self.K) if owner(self.L + k, world) == r) for r in range(world)))
+        s = 0
+        self.ct_in = s; s += 2 * self.Lr
+        self.ct_b = s; s += 2 * self.Lr
+        self.x = s; s += self.Lr
+        self.rot = s; s += self.Lr
+        self.base1 = s; s += self.Lr
+        self.y = s; s += world * self.Yr
+        self.sd = s; s += self.Mr * self.dnum
+        self.acc = s; s += 2 * self.Mr
+        self.w = s; s += world * self.Wr
+        self.out = s; s += 2 * self.Lr
+        self.s1 = s; s += 2 * self.Lr
+        self.s2 = s; s += 2 * self.Lr
+        self.slots = s
+        # constants
+        self.P = _prod(self.specials)
+        self.half = self.P // 2
+
+    def digit(self, d: int) -> List[int]:
+        return list(range(d * self.alpha, min((d + 1) * self.alpha, self.L)))
+
+    def row(self, slot: int) -> int:
+        return self.base_row + slot * self.rows
+
+    def off(self, slot: int) -> int:
+        return self.row(slot) * 1024
+
+    def y_slot(self, i: int) -> int:
+        return self.y + owner(i, self.world) * self.Yr + i // self.world
+
+    def w_slot(self, k: int, c: int) -> int:
+        r = owner(self.L + k, self.world)
+        kl = sum(1 for k2 in range(k) if owner(self.L + k2, self.world) == r)
+        return self.w + r * self.Wr + 2 * kl + c
+
+    @property
+    def spm_rows_needed(self) -> int:
+        return self.base_row + self.slots * self.rows
+
+    @property
+    def ksk_limbs(self) -> int:
+        return self.Mr * self.dnum * 2
+
+
+def _inv(a: int, q: int) -> int:
+    return pow(a % q, q - 2, q)
+
+
+def _pack(blocks: Sequence[Sequence[str]], n: int) -> List[List[str]]:
+    """Greedy packing of instruction blocks into programs that fit the 4096-word ROM."""
+    progs, cur = [], [f"vsetvl {64 * n:#x}"]
+    for b in blocks:
+        if len(b) + 2 > isa.IRAM_DEPTH:
+            raise ValueError("one block exceeds the instruction ROM")
+        if len(cur) + len(b) + 1 > isa.IRAM_DEPTH:
+            progs.append(cur + ["break"])
+            cur = [f"vsetvl {64 * n:#x}"]
+        cur += list(b)
+    progs.append(cur + ["break"])
+    return progs
+
+
+def _scalar_sum(srcs: Sequence[int], scalars: Sequence[int], dst_off: int) -> List[str]:
+    """dst = sum_t mem[srcs[t]] * scalars[t] under the current modulus, as a foldable chain."""
+    out = []
+    for t, (s, c) in enumerate(zip(srcs, scalars)):
+        if t == 0:
+            out += [f"vle v0, abs+{s:#x}", f"vfqmul.vs v6, v0, {c:#x}"]
+        else:
+            out += [f"vle v0, abs+{s:#x}", f"vfqmul.vs v3, v0, {c:#x}", "vfqadd.vv v6, v6, v3"]
+    return out + [f"vse v6, abs+{dst_off:#x}"]
+
+
+def blocks_phase1(lo: HybridLayout, mode: str) -> List[List[str]]:
+    b = []
+    a = lambda c, i: lo.off(lo.ct_in + c * lo.Lr + i)
+    bb = lambda c, i: lo.off(lo.ct_b + c * lo.Lr + i)
+    own = list(enumerate(lo.owned_ct))
+    if mode == "rotate":
+        for i, j in own:                                        # NTT-domain automorphism of both components
+            b.append(_setq(lo.moduli[j]) + [f"vle v0, abs+{a(0, i):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{lo.off(lo.rot + i):#x}",
+                                            f"vle v0, abs+{a(1, i):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{lo.off(lo.x + i):#x}"])
+    else:                                                       # tensor product
+        for i, j in own:
+            b.append(_setq(lo.moduli[j]) + [
+                f"vle v0, abs+{a(0, i):#x}", f"vle v1, abs+{bb(0, i):#x}", "vfqmul.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.rot + i):#x}",
+                f"vle v0, abs+{a(1, i):#x}", f"vle v1, abs+{bb(1, i):#x}", "vfqmul.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.x + i):#x}"])
+        for i, j in own:
+            b.append(_setq(lo.moduli[j]) + [
+                f"vle v0, abs+{a(0, i):#x}", f"vle v1, abs+{bb(1, i):#x}", "vfqmul.vv v6, v0, v1",
+                f"vle v0, abs+{a(1, i):#x}", f"vle v1, abs+{bb(0, i):#x}", "vfqmul.vv v3, v0, v1", "vfqadd.vv v6, v6, v3",
+                f"vse v6, abs+{lo.off(lo.base1 + i):#x}"])
+    for i, j in own:                                            # coefficient form
+        b.append(_setq(lo.moduli[j]) + [f"vle v0, abs+{lo.off(lo.x + i):#x}", "vintt v2, v0", f"vse v2, abs+{lo.off(lo.s1 + i):#x}"])
+    for i, j in own:                                            # times (Q_d/q_j)^-1 mod q_j
+        q = lo.moduli[j]
+        dig = lo.digit(j // lo.alpha)
+        c = _inv(_prod(lo.moduli[t] for t in dig if t != j), q)
+        b.append(_setq(q) + [f"vle v0, abs+{lo.off(lo.s1 + i):#x}", f"vfqmul.vs v2, v0, {c:#x}", f"vse v2, abs+{lo.off(lo.y_slot(j)):#x}"])
+    return b
+
+
+def blocks_modup(lo: HybridLayout) -> List[List[str]]:
+    b = []
+    for jl, j in enumerate(lo.owned_all):                       # basis extension sums
+        m = lo.mods_all[j]
+        for d in range(lo.dnum):
+            dig = lo.digit(d)
+            if j in dig:
+                continue
+            scal = [_prod(lo.moduli[t] for t in dig if t != i) % m for i in dig]
+            b.append(_setq(m) + _scalar_sum([lo.off(lo.y_slot(i)) for i in dig], scal, lo.off(lo.sd + jl * lo.dnum + d)))
+    for jl, j in enumerate(lo.owned_all):                       # to NTT form, in place
+        m = lo.mods_all[j]
+        blk = _setq(m)
+        for d in range(lo.dnum):
+            if j in lo.digit(d):
+                continue
+            s = lo.off(lo.sd + jl * lo.dnum + d)
+            blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
+        b.append(blk)
+    return b
+
+
+def blocks_inner(lo: HybridLayout) -> List[List[str]]:
+    b = []
+    for jl, j in enumerate(lo.owned_all):
+        blk = _setq(lo.mods_all[j])
+        for c in range(2):
+            acc = 6 + 2 * c
+            for d in range(lo.dnum):
+                src = lo.off(lo.x + lo.owned_ct.index(j)) if j in lo.digit(d) else lo.off(lo.sd + jl * lo.dnum + d)
+                blk += [f"vle v0, abs+{src:#x}", f"vle v1, ksk+{((jl * lo.dnum + d) * 2 + c) * 8 * lo.n:#x}"]
+                blk += [f"vfqmul.vv v{acc}, v0, v1"] if d == 0 else ["vfqmul.vv v3, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v3"]
+            blk.append(f"vse v{acc}, abs+{lo.off(lo.acc + 2 * jl + c):#x}")
+        b.append(blk)
+    return b
+
+
+def blocks_moddown_terms(lo: HybridLayout) -> List[List[str]]:
+    """Three loops (transforms, rounding constant, scaling) so that each is one batched launch; the
+    special primes' accumulators are transformed in place (they are not needed again)."""
+    b = []
+    acc = lambda k, c: lo.off(lo.acc + 2 * lo.owned_all.index(lo.L + k) + c)
+    for k in lo.owned_sp:
+        blk = _setq(lo.specials[k])
+        for c in range(2):
+            blk += [f"vle v0, abs+{acc(k, c):#x}", "vintt v2, v0", f"vse v2, abs+{acc(k, c):#x}"]
+        b.append(blk)
+    for k in lo.owned_sp:
+        p = lo.specials[k]
+        blk = _setq(p)
+        for c in range(2):
+            blk += [f"vle v0, abs+{acc(k, c):#x}", f"vfqadd.vs v2, v0, {lo.half % p:#x}", f"vse v2, abs+{acc(k, c):#x}"]
+        b.append(blk)
+    for k in lo.owned_sp:
+        p = lo.specials[k]
+        cinv = _inv(lo.P // p, p)
+        blk = _setq(p)
+        for c in range(2):
+            blk += [f"vle v0, abs+{acc(k, c):#x}", f"vfqmul.vs v2, v0, {cinv:#x}", f"vse v2, abs+{lo.off(lo.w_slot(k, c)):#x}"]
+        b.append(blk)
+    return b
+
+
+def blocks_finish(lo: HybridLayout, add_base1: bool) -> List[List[str]]:
+    b = []
+    own = list(enumerate(lo.owned_ct))
+    for i, j in own:                                            # P-basis -> q_j
+        q = lo.moduli[j]
+        blk = _setq(q)
+        for c in range(2):
+            blk += _scalar_sum([lo.off(lo.w_slot(k, c)) for k in range(lo.K)], [(lo.P // lo.specials[k]) % q for k in range(lo.K)],
+                               lo.off(lo.s1 + c * lo.Lr + i))
+        b.append(blk)
+    for i, j in own:                                            # - floor(P/2)
+        q = lo.moduli[j]
+        blk = _setq(q)
+        for c in range(2):
+            s = lo.off(lo.s1 + c * lo.Lr + i)
+            blk += [f"vle v0, abs+{s:#x}", f"vfqsub.vs v2, v0, {lo.half % q:#x}", f"vse v2, abs+{lo.off(lo.s2 + c * lo.Lr + i):#x}"]
+        b.append(blk)
+    for i, j in own:                                            # to NTT form (in place)
+        blk = _setq(lo.moduli[j])
+        for c in range(2):
+            s = lo.off(lo.s2 + c * lo.Lr + i)
+            blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
+        b.append(blk)
+    for i, j in own:                                            # acc - that
+        jl = lo.owned_all.index(j)
+        blk = _setq(lo.moduli[j])
+        for c in range(2):
+            blk += [f"vle v0, abs+{lo.off(lo.acc + 2 * jl + c):#x}", f"vle v1, abs+{lo.off(lo.s2 + c * lo.Lr + i):#x}",
+                    "vfqsub.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.s1 + c * lo.Lr + i):#x}"]
+        b.append(blk)
+    for i, j in own:                                            # times P^-1
+        q = lo.moduli[j]
+        pinv = _inv(lo.P, q)
+        b.append(_setq(q) + [
+            f"vle v0, abs+{lo.off(lo.s1 + i):#x}", f"vfqmul.vs v2, v0, {pinv:#x}", f"vse v2, abs+{lo.off(lo.s2 + i):#x}",
+            f"vle v0, abs+{lo.off(lo.s1 + lo.Lr + i):#x}", f"vfqmul.vs v2, v0, {pinv:#x}",
+            f"vse v2, abs+{lo.off((lo.s2 if add_base1 else lo.out) + lo.Lr + i):#x}"])
+    for i, j in own:                                            # + ROT (and BASE1)
+        blk = _setq(lo.moduli[j]) + [f"vle v0, abs+{lo.off(lo.s2 + i):#x}", f"vle v1, abs+{lo.off(lo.rot + i):#x}",
+                                     "vfqadd.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.out + i):#x}"]
+        if add_base1:
+            blk += [f"vle v0, abs+{lo.off(lo.s2 + lo.Lr + i):#x}", f"vle v1, abs+{lo.off(lo.base1 + i):#x}",
+                    "vfqadd.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.out + lo.Lr + i):#x}"]
+        b.append(blk)
+    return b
+
+
+class HybridKeySwitch:
+    """Rotate / multiply with the hybrid key-switch on one rank of ``world``."""
+
+    def __init__(self, vp, n: int, moduli: Sequence[int], specials: Sequence[int], alpha: int, world: int = 1, rank: int = 0,
+                 exchange: Optional[Exchange] = None, base_row: int = 0):
+        self.vp = vp
+        self.lo = lo = HybridLayout(n, moduli, specials, alpha, world, rank, base_row)
+        self.ex = exchange or Exchange()
+        asm = lambda progs: [isa.assemble("\n".join(p)) for p in progs]
+        self._p = {
+            "rot1": asm(_pack(blocks_phase1(lo, "rotate"), n)) if lo.Lr else [],
+            "mul1": asm(_pack(blocks_phase1(lo, "multiply"), n)) if lo.Lr else [],
+            "mid": asm(_pack(blocks_modup(lo) + blocks_inner(lo), n)) if lo.Mr else [],
+            "terms": asm(_pack(blocks_moddown_terms(lo), n)) if lo.owned_sp else [],
+            "fin_rot": asm(_pack(blocks_finish(lo, False), n)) if lo.Lr else [],
+            "fin_mul": asm(_pack(blocks_finish(lo, True), n)) if lo.Lr else [],
+        }
+        total = sum(len(w) for ps in self._p.values() for w in ps)
+        self._resident = total <= isa.IRAM_DEPTH
+        self._pc = {}
+        if self._resident:
+            pc = 0
+            for name, ps in self._p.items():
+                for idx, w in enumerate(ps):
+                    vp.load_isram(pc, w)
+                    self._pc[(name, idx)] = pc
+                    pc += len(w)
+
+    # -- data placement -------------------------------------------------------------------------
+    def load_key(self, key_full: np.ndarray) -> None:
+        """``key_full``: (L+K) * dnum * 2 limbs ordered [modulus][digit][component]."""
+        lo = self.lo
+        k = np.ascontiguousarray(key_full, dtype=np.uint64).reshape(lo.L + lo.K, lo.dnum * 2 * lo.n)
+        for jl, j in enumerate(lo.owned_all):
+            self.vp.write(KSK, jl * lo.dnum * 2 * lo.rows, k[j])
+
+    def _load(self, slot0: int, ct_full: np.ndarray) -> None:
+        lo = self.lo
+        ct = np.ascontiguousarray(ct_full, dtype=np.uint64).reshape(2, lo.L, lo.n)
+        for c in range(2):
+            for i, j in enumerate(lo.owned_ct):
+                self.vp.write(SPM, lo.row(slot0 + c * lo.Lr + i), ct[c, j])
+
+    def load_ct(self, ct_full: np.ndarray) -> None:
+        self._load(self.lo.ct_in, ct_full)
+
+    def load_ct_b(self, ct_full: np.ndarray) -> None:
+        self._load(self.lo.ct_b, ct_full)
+
+    def read_out(self) -> np.ndarray:
+        lo = self.lo
+        self.vp.sync()
+        return self.vp.read(SPM, lo.row(lo.out), 2 * lo.Lr * lo.n).reshape(2, lo.Lr, lo.n)
+
+    # -- the ops ----------------------------------------------------------------------------------
+    def _run(self, name: str, step: int = 0) -> None:
+        for idx, words in enumerate(self._p[name]):
+            if self._resident:
+                pc = self._pc[(name, idx)]
+            else:
+                pc = 0
+                self.vp.load_isram(0, words)
+            rc = self.vp.run(pc, src0=0, src1=0, rslt=0, ksk=0, step=step)
+            if rc:
+                raise RuntimeError(f"hybrid key-switch phase {name}[{idx}] failed with status {rc}: "
+                                   f"{getattr(self.vp, 'last_error', '')}")
+
+    def _switch(self, finish: str) -> None:
+        lo = self.lo
+        self.ex.all_gather(self.vp, lo.row(lo.y), lo.Yr * lo.n, lo.world, lo.rank)
+        self._run("mid")
+        self._run("terms")
+        self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.n, lo.world, lo.rank)
+        self._run(finish)
+
+    def rotate(self, k: int) -> None:
+        self._run("rot1", step=k)
+        self._switch("fin_rot")
+
+    def multiply(self) -> None:
+        self._run("mul1")
+        self._switch("fin_mul")

@@ -267,25 +267,29 @@ class Exchange:
         self.tensor_of = tensor_of
         self.always = always          # run the collectives even for world == 1 (single-rank NCCL smoke test)
 
-    def all_gather_digits(self, vp, lo: Layout) -> None:
-        if lo.world == 1 and not self.always:
+    def all_gather(self, vp, row0: int, chunk: int, world: int, rank: int) -> None:
+        """All-gather of ``world`` chunks of ``chunk`` words laid out back to back from SPM row ``row0``
+        (rank r owns chunk r)."""
+        if world == 1 and not self.always:
             return
         import torch
         import torch.distributed as dist
-        chunk = lo.Dr * lo.n                                   # words contributed per rank
-        row0 = lo.row(lo.dig)
+        rows = chunk // LANES
         vp.sync()
         if self.tensor_of is not None:
-            buf = self.tensor_of(vp, row0, lo.world * chunk)
-            dist.all_gather_into_tensor(buf, buf[lo.rank * chunk:(lo.rank + 1) * chunk].clone(), group=self.group)
+            buf = self.tensor_of(vp, row0, world * chunk)
+            dist.all_gather_into_tensor(buf, buf[rank * chunk:(rank + 1) * chunk].clone(), group=self.group)
             torch.cuda.current_stream().synchronize()
         else:
-            mine = torch.from_numpy(vp.read(SPM, row0 + lo.rank * lo.Dr * lo.rows, chunk).view(np.int64).copy())
-            parts = [torch.empty_like(mine) for _ in range(lo.world)]
+            mine = torch.from_numpy(vp.read(SPM, row0 + rank * rows, chunk).view(np.int64).copy())
+            parts = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(parts, mine, group=self.group)
             for r, p in enumerate(parts):
-                if r != lo.rank:
-                    vp.write(SPM, row0 + r * lo.Dr * lo.rows, p.numpy().view(np.uint64))
+                if r != rank:
+                    vp.write(SPM, row0 + r * rows, p.numpy().view(np.uint64))
+
+    def all_gather_digits(self, vp, lo: Layout) -> None:
+        self.all_gather(vp, lo.row(lo.dig), lo.Dr * lo.n, lo.world, lo.rank)
 
     def broadcast_terms(self, vp, lo: Layout) -> None:
         if lo.world == 1 and not self.always:

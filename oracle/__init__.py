@@ -60,6 +60,7 @@ def lib() -> C.CDLL:
         L.orc_ntt.restype = None; L.orc_ntt.argtypes = [p, C.c_uint, u64, p]
         L.orc_intt.restype = None; L.orc_intt.argtypes = [p, C.c_uint, u64, p]
         L.orc_vaut.restype = None; L.orc_vaut.argtypes = [p, p, C.c_uint, u64, u64]
+        L.orc_vautn.restype = None; L.orc_vautn.argtypes = [p, p, C.c_uint, u64]
         L.orc_vroli.restype = None; L.orc_vroli.argtypes = [p, p, C.c_uint, u64]
         L.orc_ntt_batch.restype = C.c_int; L.orc_ntt_batch.argtypes = [p, C.c_uint, u64, C.c_uint, C.c_int]
         L.orc_vp_create.restype = p; L.orc_vp_create.argtypes = [u64, u64]
@@ -130,6 +131,13 @@ def intt(a, q): return ntt(a, q, inverse=True)
 def vaut(a, q, k):
     a = _u64(a); out = np.empty_like(a)
     lib().orc_vaut(out.ctypes.data, a.ctypes.data, a.size.bit_length() - 1, q, k)
+    return out
+
+
+def vautn(a, k):
+    """Extension: the automorphism of ``vaut`` on an NTT-form limb (a permutation, no modulus)."""
+    a = _u64(a); out = np.empty_like(a)
+    lib().orc_vautn(out.ctypes.data, a.ctypes.data, a.size.bit_length() - 1, k)
     return out
 
 

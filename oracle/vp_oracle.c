@@ -260,6 +260,27 @@ void orc_vaut(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t q, uint
   }
 }
 
+/* vautn -- EXTENSION (funct6 011101, not in the reference): the automorphism of vaut applied to a
+ * limb in NTT form, i.e. to the bit-reversed evaluations that vntt produces.  vntt puts
+ * x(psi^(2*brv(j)+1)) at index j (tf_rom_generator.sv:28-30 twiddle order), and
+ * sigma_k(x)(psi^e) = x(psi^(e*k)), so the result is a pure permutation, no signs:
+ *     out[j] = in[brv(((2*brv(j)+1) * k mod 2N - 1) / 2)]
+ * with the exponent reduced mod N exactly as vaut reduces it, so that
+ * vntt(vaut(x, k)) == vautn(vntt(x), k) for every operand k (tests). */
+static uint64_t brv(uint64_t x, unsigned bits) {
+  uint64_t r = 0;
+  for (unsigned b = 0; b < bits; b++) r |= ((x >> b) & 1) << (bits - 1 - b);
+  return r;
+}
+void orc_vautn(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t k) {
+  uint64_t n = 1ull << logn;
+  uint64_t ke = k & (n - 1);
+  for (uint64_t j = 0; j < n; j++) {
+    uint64_t e = ((2 * brv(j, logn) + 1) * ke) & (2 * n - 1);
+    out[j] = in[brv((e - 1) >> 1, logn)];
+  }
+}
+
 /* vroli.  vxu_lane.sv:595,:597; model vxu_top_tb.sv:619-623: out[(i + N - s) mod N] = in[i] */
 void orc_vroli(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t s) {
   uint64_t n = 1ull << logn;
@@ -408,7 +429,7 @@ int orc_vp_run(orc_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
       int rc = vl_logn(vp->vl_bits, &logn);
       if (rc) return rc;
       n = 1ull << logn;
-      if (funct6 != 0x03 && funct6 != 0x07 && funct6 != 0x19) {     /* arithmetic needs q */
+      if (funct6 != 0x03 && funct6 != 0x07 && funct6 != 0x19 && funct6 != 0x1d) {     /* arithmetic needs q */
         if (q <= (1ull << 59) || q >= (1ull << 60)) return ORC_ERR_MODULUS;
       }
     }
@@ -451,13 +472,16 @@ int orc_vp_run(orc_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
         for (uint64_t i = 0; i < n; i++) orc_alu(0x05, a[i], 0, 0, q, &d[i], NULL);
         break;
       }
-      case 0x15: case 0x19: {                                     /* vaut / vroli :460-501,:549-558 */
+      case 0x15: case 0x19: case 0x1d: {                          /* vaut / vroli :460-501,:549-558; vautn: extension */
         uint64_t k = step + imm;                                  /* scalar_iconn = csr_step + imm */
         uint64_t *tmp = (uint64_t *)malloc(n * 8);
         if (!tmp) return ORC_ERR_ARG;
         if (funct6 == 0x15) {
           if (!(k & 1)) { free(tmp); return ORC_ERR_AUT; }
           orc_vaut(tmp, vp->vreg[vs1], logn, q, k);
+        } else if (funct6 == 0x1d) {
+          if (!(k & 1)) { free(tmp); return ORC_ERR_AUT; }
+          orc_vautn(tmp, vp->vreg[vs1], logn, k);
         } else {
           orc_vroli(tmp, vp->vreg[vs1], logn, k);
         }

@@ -112,3 +112,26 @@ class ToyCKKS:
                 key[j, d, 1] = a
                 key[j, d, 0] = np.array([(int(v) - int(u) * int(w)) % m for u, v, w in zip(a, pe, s_hat)], dtype=np.uint64)
         return key.reshape(-1, self.n)
+
+    def switch_key_hybrid(self, s_from, specials, alpha):
+        """Hybrid key (dnum = ceil(L/alpha) digits, P = prod specials): ((L+K)*dnum*2, n) limbs
+        [modulus][digit][component]; digit d carries P*s_from under the primes of D_d, 0 elsewhere."""
+        L = self.L
+        specials = [int(p) for p in specials]
+        mods = self.moduli + specials
+        P = 1
+        for p in specials:
+            P *= p
+        dnum = -(-L // alpha)
+        key = np.empty((len(mods), dnum, 2, self.n), dtype=np.uint64)
+        for d in range(dnum):
+            e = self.small_error()
+            members = range(d * alpha, min((d + 1) * alpha, L))
+            for j, m in enumerate(mods):
+                a = self.uniform(m)
+                s_hat = self.ntt(self.s, m)
+                payload = [(P % m) * x for x in s_from] if j in members else [0] * self.n
+                pe = self.ntt([x + y for x, y in zip(payload, e)], m)
+                key[j, d, 1] = a
+                key[j, d, 0] = np.array([(int(v) - int(u) * int(w)) % m for u, v, w in zip(a, pe, s_hat)], dtype=np.uint64)
+        return key.reshape(-1, self.n)

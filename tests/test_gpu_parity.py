@@ -258,6 +258,29 @@ def test_vaut_vroli_match_oracle(engine, logn):
         assert np.array_equal(got[2], oracle.vroli(exp, k + k % 97))
 
 
+@pytest.mark.parametrize("logn", [10, 13, 16])
+def test_vautn_extension_matches_oracle(engine, logn):
+    """vautn (NTT-form automorphism): fused batch (vle; vautn; vse), register form, and the identity
+    vntt(vaut(x)) == vautn(vntt(x)) evaluated on the engine itself."""
+    n = 1 << logn
+    rows = n // 128
+    rng = np.random.default_rng(600 + logn)
+    q = Q1 if logn == 13 else oracle.nth_prime(logn, 1)
+    a = residues(rng, n, q)
+    for k in (3, pow(3, 5, 2 * n), n + 7, 2 * n - 1):
+        prog = f"vsetvl {64 * n:#x}\nvsetq {q:#x}\nvle v0, src0+0x0\nvautn v2, v0, 0x0\nvse v2, rslt+0x0\n" \
+               f"vle v1, src0+0x0\nvautn v1, v1, 0x0\nvcp v3, v1\nvse v3, rslt+{8 * n:#x}\n" \
+               f"vle v4, src0+0x0\nvaut v6, v4, 0x0\nvntt v8, v6\nvse v8, rslt+{16 * n:#x}\n" \
+               f"vle v5, src0+0x0\nvntt v7, v5\nvautn v9, v7, 0x0\nvse v9, rslt+{24 * n:#x}\nbreak"
+        engine.write(SPM, 0, a)
+        assert _run_asm(engine, prog, src0=0, rslt=rows, step=k) == 0
+        got = engine.read(SPM, rows, 4 * n).reshape(4, n)
+        assert np.array_equal(got[0], oracle.vautn(a, k)), f"fused vautn k={k}"
+        assert np.array_equal(got[1], oracle.vautn(a, k)), f"register vautn k={k}"
+        assert np.array_equal(got[2], got[3]), f"vntt(vaut) != vautn(vntt), k={k}"
+        assert np.array_equal(got[3], oracle.vautn(oracle.ntt(a, q), k))
+
+
 def test_sequencer_fusion_is_exact_and_batches(engine):
     """the fusing sequencer (zero-copy vle, direct stores, batched vle->vntt->vse
     runs) must leave every byte a vse writes identical to plain sequential execution."""

@@ -1,0 +1,161 @@
+"""Hybrid key-switch (several primes per digit, NTT-domain automorphism).
+
+Pinning: at alpha = 1, K = 1 the generalisation is the reference's own algorithm and must give
+the reference's golden rotate bit for bit.  For alpha > 1 there are no reference vectors: the
+programs are checked for what they mean (exact-integer decryption) on the oracle's ISA machine,
+sharded vs single rank over gloo, and GPU vs oracle bit-exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from aloha_amd import hybrid, keyswitch
+from util import N, P, Q0, Q1, load, manifest
+
+
+def _setup(n, L, K, seed):
+    logn = n.bit_length() - 1
+    mods = [oracle.nth_prime(logn, i) for i in range(L)]
+    specials = [oracle.nth_prime(logn, L + k) for k in range(K)]
+    return mods, specials
+
+
+def _random_case(n, L, K, alpha, seed):
+    mods, specials = _setup(n, L, K, seed)
+    rng = np.random.default_rng(seed)
+    dnum = -(-L // alpha)
+    ct = np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
+    key = np.stack([rng.integers(0, (mods + specials)[j], n, dtype=np.uint64) for j in range(L + K) for _ in range(2 * dnum)])
+    return mods, specials, ct, key
+
+
+def _run(vp, n, mods, specials, alpha, ct, key, op, k=0, **kw):
+    hs = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha, **kw)
+    hs.load_key(key); hs.load_ct(ct)
+    if op == "multiply":
+        hs.load_ct_b(ct[::-1].copy()); hs.multiply()
+    else:
+        hs.rotate(k)
+    return hs
+
+
+@pytest.mark.parametrize("case,kern,step", [("case0", "kernel1", 2), ("case1", "kernel12", 4)])
+def test_alpha1_reproduces_the_reference_golden_rotate(case, kern, step):
+    """alpha = 1, K = 1 on the reference's primes and keys: == tv/ ct_after_rotate, bit for bit
+    (vautn + iNTT in place of iNTT + vaut, scalar-1 basis conversions in place of vcp/vfqmod)."""
+    m = manifest()[case]
+    ct = load(m[f"{kern}_ct_before_rotate"]).reshape(4, N)
+    exp = load(m[f"{kern}_ct_after_rotate"]).reshape(2, 2, N)
+    hs = _run(oracle.OracleVP(), N, [Q0, Q1], [P], 1, ct, load(m[f"ksk_step{step}"]), "rotate", pow(3, step, 2 * N))
+    assert np.array_equal(hs.read_out(), exp)
+
+
+def _toy(n, L, K, seed):
+    from ckks_toy import ToyCKKS
+    mods, specials = _setup(n, L, K, seed)
+    return ToyCKKS(n, mods, specials[0], seed), specials
+
+
+@pytest.mark.parametrize("alpha,K", [(2, 2), (3, 3)])   # K >= alpha: P must exceed every digit modulus Q_d
+def test_hybrid_rotate_and_multiply_decrypt_correctly(alpha, K):
+    """Exact-integer semantics, N = 1024, L = 4 (alpha = 3: a ragged last digit)."""
+    n, L = 1024, 4
+    toy, specials = _toy(n, L, K, 13)
+    rng = np.random.default_rng(8)
+    k = pow(3, 7, 2 * n)
+    m = [int(x) << 30 for x in rng.integers(-1000, 1000, n)]
+    ct = toy.encrypt(m)
+    key = toy.switch_key_hybrid(toy.automorph(toy.s, k), specials, alpha)
+    hs = _run(oracle.OracleVP(spm_rows=1 << 14, ksk_rows=1 << 14), n, toy.moduli, specials, alpha, ct.reshape(2 * L, n), key, "rotate", k)
+    got = toy.decrypt(hs.read_out())
+    exp = toy.automorph(m, k)
+    assert max(abs(a - b) for a, b in zip(got, exp)) < 1 << 22
+    ma = [int(x) << 20 for x in rng.integers(-100, 100, n)]
+    mb = [int(x) << 20 for x in rng.integers(-100, 100, n)]
+    cta, ctb = toy.encrypt(ma), toy.encrypt(mb)
+    key = toy.switch_key_hybrid(toy.negacyclic(toy.s, toy.s), specials, alpha)
+    hs = hybrid.HybridKeySwitch(oracle.OracleVP(spm_rows=1 << 14, ksk_rows=1 << 14), n, toy.moduli, specials, alpha)
+    hs.load_key(key); hs.load_ct(cta.reshape(2 * L, n)); hs.load_ct_b(ctb.reshape(2 * L, n))
+    hs.multiply()
+    got = toy.decrypt(hs.read_out())
+    exp = toy.negacyclic(ma, mb)
+    assert max(abs(a - b) for a, b in zip(got, exp)) < 1 << 36 and max(abs(x) for x in exp) > 1 << 50
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, L, K, alpha, seed, k, op, out_dir, engine):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mods, specials, ct, key = _random_case(n, L, K, alpha, seed)
+        if engine == "gpu":
+            from aloha_amd import vp as avp
+            vp = avp.VP(spm_rows=1 << 15, ksk_rows=1 << 15, max_log_n=16, device=0)
+        else:
+            vp = oracle.OracleVP(spm_rows=1 << 14, ksk_rows=1 << 14)
+        hs = _run(vp, n, mods, specials, alpha, ct, key, op, k, world=world, rank=rank,
+                  exchange=keyswitch.Exchange(group=None, tensor_of=None))
+        np.save(os.path.join(out_dir, f"out{rank}.npy"), hs.read_out())
+        np.save(os.path.join(out_dir, f"own{rank}.npy"), np.array(hs.lo.owned_ct))
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_sharded(tmp_path, n, L, K, alpha, op, engine):
+    seed, k = 17, pow(3, 5, 2 * n)
+    mods, specials, ct, key = _random_case(n, L, K, alpha, seed)
+    exp = _run(oracle.OracleVP(spm_rows=1 << 15, ksk_rows=1 << 15), n, mods, specials, alpha, ct, key, op, k).read_out()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, L, K, alpha, seed, k, op, str(tmp_path), engine), nprocs=2, join=True)
+    seen = set()
+    for r in range(2):
+        out = np.load(tmp_path / f"out{r}.npy")
+        own = np.load(tmp_path / f"own{r}.npy")
+        for i, j in enumerate(own):
+            assert np.array_equal(out[:, i], exp[:, j]), f"rank {r} limb {j}"
+            seen.add(int(j))
+    assert seen == set(range(L))
+
+
+@pytest.mark.parametrize("op", ["rotate", "multiply"])
+def test_two_rank_hybrid_gloo(tmp_path, op):
+    """L = 5, K = 2, alpha = 2 over two ranks (uneven shards, a special prime on each rank)."""
+    _check_sharded(tmp_path, 1024, 5, 2, 2, op, "oracle")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", ["rotate", "multiply"])
+def test_two_rank_hybrid_real_engines(tmp_path, op):
+    _check_sharded(tmp_path, 4096, 5, 2, 2, op, "gpu")
+
+
+@pytest.mark.gpu
+def test_hybrid_on_gpu_matches_oracle_and_golden():
+    from aloha_amd import vp as avp
+    # the golden rotate through the hybrid programs at alpha = 1, on the GPU
+    m = manifest()["case0"]
+    ct = load(m["kernel1_ct_before_rotate"]).reshape(4, N)
+    exp = load(m["kernel1_ct_after_rotate"]).reshape(2, 2, N)
+    with avp.VP(spm_rows=1 << 16, ksk_rows=1 << 16, max_log_n=16) as vp:
+        hs = _run(vp, N, [Q0, Q1], [P], 1, ct, load(m["ksk_step2"]), "rotate", pow(3, 2, 2 * N))
+        assert np.array_equal(hs.read_out(), exp)
+    # N = 2^16, L = 6, K = 2, alpha = 2 and 4 (ragged): GPU == oracle machine, rotate and multiply
+    n, L, K = 1 << 16, 6, 2
+    for alpha in (2, 4):
+        mods, specials, ct, key = _random_case(n, L, K, alpha, 40 + alpha)
+        lo = hybrid.HybridLayout(n, mods, specials, alpha)
+        for op in ("rotate", "multiply"):
+            k = pow(3, 3, 2 * n)
+            exp = _run(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows), n, mods, specials, alpha,
+                       ct, key, op, k).read_out()
+            with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
+                got = _run(vp, n, mods, specials, alpha, ct, key, op, k).read_out()
+            assert np.array_equal(got, exp), (alpha, op)
