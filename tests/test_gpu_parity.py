@@ -360,7 +360,7 @@ def _random_program(rng, n, primes, nslots, length):
         return f"src0+{int(rng.integers(nslots)) * 8 * n:#x}"
 
     for _ in range(length):
-        op = rng.choice(["vle", "vle", "vse", "vv", "vs", "un", "perm", "ntt", "setq", "dot"])
+        op = rng.choice(["vle", "vle", "vse", "vv", "vs", "un", "perm", "ntt", "setq", "dot", "sdot", "stores"])
         vd = int(rng.choice(regs))
         if op == "vle":
             lines.append(f"vle v{vd}, {slot()}"); defined.add(vd)
@@ -390,7 +390,7 @@ def _random_program(rng, n, primes, nslots, length):
                 # (the raw `q - x` of vaut needs a canonical x: real programs permute iNTT outputs)
                 t2 = int(rng.choice(regs))
                 lines.append(f"vcp v{t2}, v{a}")
-                lines.append(f"{rng.choice(['vaut', 'vroli'])} v{vd}, v{t2}, {2 * int(rng.integers(8)):#x}")
+                lines.append(f"{rng.choice(['vaut', 'vroli', 'vautn'])} v{vd}, v{t2}, {2 * int(rng.integers(8)):#x}")
                 defined.update({t2, vd})
         elif op == "ntt":
             a = pick_def()
@@ -407,12 +407,35 @@ def _random_program(rng, n, primes, nslots, length):
             defined.update({0, 1, acc}); defined.add(t) if i else None
             if rng.integers(2):
                 lines.append(f"vse v{acc}, {slot()}")
+        elif op == "sdot":                                   # the basis-conversion idiom: memory operands times scalars, summed
+            acc, t = 6, 3
+            mixed = bool(rng.integers(2))
+            for i in range(int(rng.integers(1, 5))):
+                sc = int(rng.integers(1, 1 << 60))
+                if mixed and i % 2:
+                    lines += [f"vle v0, {slot()}", f"vle v1, {slot()}"]
+                    lines += [f"vfqmul.vv v{acc}, v0, v1"] if i == 0 else [f"vfqmul.vv v{t}, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v{t}"]
+                    defined.add(1)
+                else:
+                    lines += [f"vle v0, {slot()}"]
+                    lines += [f"vfqmul.vs v{acc}, v0, {sc:#x}"] if i == 0 else [f"vfqmul.vs v{t}, v0, {sc:#x}", f"vfqadd.vv v{acc}, v{acc}, v{t}"]
+            defined.update({0, acc}); defined.add(t) if i else None
+            choice = int(rng.integers(3))
+            if choice == 0:
+                lines.append(f"vse v{acc}, {slot()}")
+            elif choice == 1:                                # a lazy value read by another op: must be evaluated first
+                lines.append(f"vfqsub.vs v2, v{acc}, {int(rng.integers(1, 1 << 59)):#x}"); defined.add(2)
+        elif op == "stores":                                 # several sums stored back to back (one deferred launch), with hazards
+            for _ in range(int(rng.integers(2, 4))):
+                lines += [f"vle v0, {slot()}", f"vle v1, {slot()}", "vfqmul.vv v6, v0, v1", f"vle v0, {slot()}",
+                          f"vfqmul.vs v3, v0, {int(rng.integers(1, 1 << 59)):#x}", "vfqadd.vv v6, v6, v3", f"vse v6, {slot()}"]
+            defined.update({0, 1, 3, 6})
     for r in sorted(defined):                                # flush every live register to memory
         lines.append(f"vse v{r}, src0+{(nslots + r) * 8 * n:#x}")
     return "\n".join(lines + ["break"])
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(32))
 def test_random_programs_fused_unfused_oracle(engine, seed):
     """Differential fuzz of the sequencer: fused engine == unfused engine == oracle on all memory."""
     rng = np.random.default_rng(1000 + seed)
@@ -421,7 +444,7 @@ def test_random_programs_fused_unfused_oracle(engine, seed):
     primes = [oracle.nth_prime(13, i) for i in range(2)]          # q = 1 mod 2^14 serves every N <= 8192
     mem = np.stack([residues(rng, n, primes[0]) for _ in range(nslots)])
     mem[1, :8] = 0                                                # zeros exercise the flipped-zero corner of vaut
-    words = isa.assemble(_random_program(rng, n, primes, nslots, 40))
+    words = isa.assemble(_random_program(rng, n, primes, nslots, 40 if seed < 12 else 70))
     total = (nslots + 10) * n
     plain = avp.VP(spm_rows=(nslots + 10) * rows, ksk_rows=1, max_log_n=13, flags=avp.FLAG_NO_FUSION)
     o = oracle.OracleVP(spm_rows=(nslots + 10) * rows, ksk_rows=1)
