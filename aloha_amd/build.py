@@ -17,8 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libaloha_vp.so")
-SOURCES = ["vp_engine.cpp", "numtheory.cpp", "ew_kernels.hip", "ntt_tile.hip", "encode_kernels.hip"]
-HEADERS = ["kernels.hpp", "modarith.hpp", "numtheory.hpp", os.path.join("..", "..", "include", "aloha_vp.h")]
+SOURCES = ["vp_engine.cpp", "numtheory.cpp", "ew_kernels.hip", "ntt_tile.hip", "ntt_single.hip", "encode_kernels.hip"]
+HEADERS = ["kernels.hpp", "modarith.hpp", "ntt_device.hpp", "numtheory.hpp", os.path.join("..", "..", "include", "aloha_vp.h")]
 ARCH = "gfx950"
 
 

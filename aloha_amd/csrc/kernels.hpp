@@ -119,7 +119,13 @@ hipError_t ntt_radix2_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDe
 hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *d_inplace,
                           const PrimeDev *d_primes, uint32_t begin, uint32_t count, unsigned logn,
                           bool inverse, const TileDesc *d_uni_tiles, uint32_t n_uni,
-                          const TileDesc *d_glb_tiles, uint32_t n_glb, uint64_t *launches);
+                          const TileDesc *d_glb_tiles, uint32_t n_glb, uint64_t *launches,
+                          unsigned single_max = 13);   // largest log2 N transformed by the single-pass kernels (0: never)
+
+// Single-pass transforms for N = 2^12 .. 2^14 (the limb stays in one CU's LDS: one read + one write of
+// the limb, ntt_single.hip); d_jobs = the {src, dst} entries of the limbs to transform.
+hipError_t ntt_single_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
+                            unsigned logn, bool inverse, uint64_t *launches);
 
 // ---- CKKS encoder block (src/encoder), FP64: see encode_kernels.hip --------------------------------
 struct EncodeTables {      // per ring size N = 2^logn, n = N/2 slots; built by the host (vp_engine.cpp)

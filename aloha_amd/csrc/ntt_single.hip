@@ -1,0 +1,201 @@
+// ntt_single.hip -- single-pass negacyclic NTT / iNTT for N = 2^12, 2^13, 2^14 (gfx950).
+//
+// A limb of these sizes (32 / 64 / 128 KiB) fits the CU's 160 KiB LDS, so the whole transform is
+// ONE read and ONE write of the limb: HBM traffic = the algorithmic 16*N bytes, where the
+// two-pass tiles of ntt_tile.hip move twice that.  N = 2^13 is the reference's own size (every
+// tv/ vector, every shipped program), N = 2^12 / 2^14 are BASELINE configs 2 / 3.
+// Same results as every other path: natural order in -> bit-reversed out, twiddle
+// psi^bitrev(m+i) (tf_rom_generator.sv:28-63), canonical outputs.
+//
+// One workgroup of T = N/16 threads per limb, 16 values per thread in registers, the limb in LDS
+// between steps.  The log2 N stages are cut into radix-16 register steps over descending groups
+// of four index bits, plus E = log2 N - 12 trailing stages:
+//     L0  registers = index bits [n-1 .. n-4]     e = r*T + t            loads (coalesced 8 B lanes)
+//     L1  registers = bits [n-5 .. n-8]
+//     L2  registers = bits [n-9 .. n-12]
+//     L3  registers = top 4-E bits and low E bits e = rhi*(N >> (4-E)) + t*2^E + rlo
+//                                                                         stores (8*2^E B per lane, coalesced)
+// with an LDS exchange between consecutive layouts (three per transform).  Elements with equal top
+// four index bits form a REGION of N/16 words; in L1 and L2 a thread's registers and the threads of a
+// wave stay inside regions owned by that wave (16 / 32 / 64 consecutive threads per region), so the
+// middle exchange is wave-private (no s_barrier, wave_lds_fence) and a wave only ever writes its own
+// regions outside the first write phase: two workgroup barriers per transform.  LDS word of element
+// e: e ^ ((e >> 4) & 31) [^ ((e >> 5) & 31) for n > 12] -- a bijection under which every
+// wave-instruction of every layout touches 32 distinct 8-byte banks per half-wave (checked
+// exhaustively; no padding, so the limb occupies exactly N*8 bytes: 5 / 2 / 1 workgroups per CU).
+// Stage s uses twiddle entry 2^s + (e >> (n - s)) of the plain table: for the first step that
+// depends on the register index only (scalar loads), afterwards on the thread's upper bits
+// (vector loads, 16 B per lane).  The inverse runs the same steps backwards with the
+// Gentleman-Sande butterflies and fuses N^-1 into the last one.
+#include "kernels.hpp"
+#include "modarith.hpp"
+#include "ntt_device.hpp"
+
+namespace aloha {
+namespace k {
+
+namespace {
+
+template <int LOGN>
+__device__ __forceinline__ uint32_t swz(uint32_t e) {
+  return LOGN == 12 ? e ^ ((e >> 4) & 31) : e ^ ((e >> 4) & 31) ^ ((e >> 5) & 31);
+}
+
+// layouts: element index held in register r of thread t
+template <int LOGN, int K>      // K = 0, 1, 2: registers = index bits [LOGN-1-4K .. LOGN-4-4K]
+__device__ __forceinline__ uint32_t lay(uint32_t t, uint32_t r) {
+  constexpr int P = LOGN - 4 - 4 * K;
+  return ((t >> P) << (P + 4)) | (r << P) | (t & ((1u << P) - 1));
+}
+template <int LOGN>             // final layout
+__device__ __forceinline__ uint32_t lay3(uint32_t t, uint32_t r) {
+  constexpr int E = LOGN - 12;
+  return (r >> E) * ((1u << LOGN) >> (4 - E)) + (t << E) + (r & ((1u << E) - 1));
+}
+
+// twiddles of a radix-16 step over stages 4K .. 4K+3 for a thread whose upper index bits are A:
+// entry 2^(4K+ss) + A*2^ss + g of the plain (w, w') table
+struct TwPlain {
+  ctw_t tab;
+  uint32_t base, a;              // base = 2^(4K)
+  __device__ __forceinline__ tw_t operator()(int ss, int g) const { return load_tw(tab + (base << ss) + (a << ss) + g); }
+};
+
+template <int LOGN, bool INV>
+__global__ __launch_bounds__((1 << LOGN) / 16) void ntt_single_kernel(const LimbJob *__restrict__ jobs,
+                                                                       const PrimeDev *__restrict__ primes) {
+  constexpr int N = 1 << LOGN, T = N / 16, E = LOGN - 12, NH = 16 >> E;     // NH = groups of 2^E registers in L3
+  extern __shared__ __attribute__((aligned(16))) u64 lds[];
+  const uint32_t t = threadIdx.x;
+  const LimbJob jb = jobs[blockIdx.x];
+  const PrimeDev *pr = &primes[jb.prime];
+  const u64 q = pr->m.q, nq = pr->m.nq;
+  ctw_t tab = (ctw_t)(INV ? pr->tw.inv : pr->tw.fwd);
+  cgptr_t src = (cgptr_t)jb.src;
+  gptr_t dst = (gptr_t)jb.dst;
+  const uint32_t a1 = t >> (LOGN - 8), a2 = t >> E;           // upper index bits of the thread in L1 / L2
+  u64 v[16];
+
+  auto exchange = [&](auto from, auto to, bool wave_private) {   // registers: layout `from` -> layout `to`
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds[swz<LOGN>(from(t, r))] = v[r];
+    if (wave_private) wave_lds_fence(); else __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = lds[swz<LOGN>(to(t, r))];
+    if (wave_private) wave_lds_fence();                        // (the next write phase reuses the same words)
+  };
+  auto L0 = [](uint32_t tt, uint32_t r) { return lay<LOGN, 0>(tt, r); };
+  auto L1 = [](uint32_t tt, uint32_t r) { return lay<LOGN, 1>(tt, r); };
+  auto L2 = [](uint32_t tt, uint32_t r) { return lay<LOGN, 2>(tt, r); };
+  auto L3 = [](uint32_t tt, uint32_t r) { return lay3<LOGN>(tt, r); };
+
+  if (!INV) {
+    constexpr int B0 = FWD_IN, B1 = bound_after4(B0), B2 = bound_after4(B1), B3 = bound_after4(B2);
+    constexpr int B4 = next_bound(B3), B5 = next_bound(B4);
+    static_assert(B3 <= 16 && B4 <= 16 && B5 <= 16, "forward lazy range overflows");
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = ld_stream(src + r * T + t);
+    fwd_radix16<true, B0>(v, TwPlain{tab, 1, 0}, q, nq);                       // stages 0..3
+    exchange(L0, L1, false);
+    fwd_radix16<false, B1>(v, TwPlain{tab, 16, a1}, q, nq);                    // stages 4..7
+    exchange(L1, L2, true);
+    fwd_radix16<false, B2>(v, TwPlain{tab, 256, a2}, q, nq);                   // stages 8..11
+    exchange(L2, L3, false);
+    const u64 fourq = q << 2;
+    if (E == 1) {                                              // stage 12: pairs (2h, 2h+1), group e >> 1 = h*T + t
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+        const tw_t w = load_tw(tab + 4096 + h * T + t);
+        if (need_corr(B3)) v[2 * h] = csub_borrow(v[2 * h], q * (u64)corr_t(B3));
+        ct_bfly<false, false>(v[2 * h], v[2 * h + 1], w.w, w.wp, nq, fourq);
+      }
+    } else if (E == 2) {                                       // stage 12: bit 1 (group e >> 2 = h*T + t); stage 13: bit 0
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+        const tw_t w = load_tw(tab + 4096 + h * T + t);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if (need_corr(B3)) v[4 * h + j] = csub_borrow(v[4 * h + j], q * (u64)corr_t(B3));
+          ct_bfly<false, false>(v[4 * h + j], v[4 * h + j + 2], w.w, w.wp, nq, fourq);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {                          // group e >> 1 = h*(N/8) + 2t + j
+          const tw_t w = load_tw(tab + 8192 + h * (N / 8) + 2 * t + j);
+          if (need_corr(B4)) v[4 * h + 2 * j] = csub_borrow(v[4 * h + 2 * j], q * (u64)corr_t(B4));
+          ct_bfly<false, false>(v[4 * h + 2 * j], v[4 * h + 2 * j + 1], w.w, w.wp, nq, fourq);
+        }
+    }
+    const u32 kc = (u32)pr->m.kc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) st_stream(dst + lay3<LOGN>(t, r), canon_any(v[r], q, nq, kc));
+  } else {
+    const u64 fourq = q << 2;
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = ld_stream(src + lay3<LOGN>(t, r));     // < 2^60 < 4q
+    if (E == 2) {
+#pragma unroll
+      for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const tw_t w = load_tw(tab + 8192 + h * (N / 8) + 2 * t + j);
+          gs_bfly<false>(v[4 * h + 2 * j], v[4 * h + 2 * j + 1], w.w, w.wp, nq, fourq);
+        }
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+        const tw_t w = load_tw(tab + 4096 + h * T + t);
+#pragma unroll
+        for (int j = 0; j < 2; j++) gs_bfly<false>(v[4 * h + j], v[4 * h + j + 2], w.w, w.wp, nq, fourq);
+      }
+    } else if (E == 1) {
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+        const tw_t w = load_tw(tab + 4096 + h * T + t);
+        gs_bfly<false>(v[2 * h], v[2 * h + 1], w.w, w.wp, nq, fourq);
+      }
+    }
+    exchange(L3, L2, false);
+    inv_radix16<false>(v, TwPlain{tab, 256, a2}, q, nq);                       // stages 11..8
+    exchange(L2, L1, true);
+    inv_radix16<false>(v, TwPlain{tab, 16, a1}, q, nq);                        // stages 7..4
+    exchange(L1, L0, false);
+    inv_radix16<true>(v, TwPlain{tab, 1, 0}, q, nq);                           // stages 3..0
+    const u64 ni = pr->tw.n_inv, nip = pr->tw.n_inv_shoup;
+#pragma unroll
+    for (int r = 0; r < 16; r++) st_stream(dst + r * T + t, scale_canon(v[r], ni, nip, q, nq));
+  }
+}
+
+template <int LOGN, bool INV>
+hipError_t launch_single(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count) {
+  constexpr int N = 1 << LOGN;
+  const void *fn = reinterpret_cast<const void *>(&ntt_single_kernel<LOGN, INV>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, N * 8);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((ntt_single_kernel<LOGN, INV>), dim3(count), dim3(N / 16), N * 8, st, d_jobs, d_primes);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t ntt_single_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count, unsigned logn,
+                            bool inverse, uint64_t *launches) {
+  if (!count) return hipSuccess;
+  hipError_t e;
+  switch (logn * 2 + (inverse ? 1 : 0)) {
+    case 24: e = launch_single<12, false>(st, d_jobs, d_primes, count); break;
+    case 25: e = launch_single<12, true>(st, d_jobs, d_primes, count); break;
+    case 26: e = launch_single<13, false>(st, d_jobs, d_primes, count); break;
+    case 27: e = launch_single<13, true>(st, d_jobs, d_primes, count); break;
+    case 28: e = launch_single<14, false>(st, d_jobs, d_primes, count); break;
+    case 29: e = launch_single<14, true>(st, d_jobs, d_primes, count); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (launches) ++*launches;
+  return e;
+}
+
+}  // namespace k
+}  // namespace aloha

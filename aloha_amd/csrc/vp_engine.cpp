@@ -260,7 +260,8 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
     for (const PlanChunk &pc : plan->chunks) {
       e = aloha::k::ntt_tile_batch(vp->stream, plan->d_jobs, plan->d_jobs + count, vp->d_primes, pc.limb_begin,
                                    pc.limb_count, logn, inverse, plan->d_tiles + pc.uni_off, pc.n_uni,
-                                   plan->d_tiles + pc.glb_off, pc.n_glb, &launches);
+                                   plan->d_tiles + pc.glb_off, pc.n_glb, &launches,
+                                   (vp->flags & ALOHA_FLAG_NTT_TWO_PASS) ? 0u : (vp->flags & ALOHA_FLAG_NTT_SINGLE_14) ? 14u : 13u);
       if (e != hipSuccess) break;
     }
   }

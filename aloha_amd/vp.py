@@ -24,6 +24,8 @@ ROW_BYTES = 1024
 LANES = 128
 FLAG_NO_FUSION = 1
 FLAG_RADIX2_ONLY = 2
+FLAG_NTT_TWO_PASS = 4
+FLAG_NTT_SINGLE_14 = 8
 
 STATUS = ["OK", "ERR_ARG", "ERR_VL", "ERR_MODULUS", "ERR_ROOT", "ERR_DECODE", "ERR_BANK", "ERR_ADDR",
           "ERR_AUT", "ERR_NOBREAK", "ERR_DEVICE", "ERR_NOMEM"]

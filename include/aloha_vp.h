@@ -77,6 +77,8 @@ typedef struct {
 
 #define ALOHA_FLAG_NO_FUSION 1u    /* one kernel per instruction (debug / parity bisecting)  */
 #define ALOHA_FLAG_RADIX2_ONLY 2u /* transforms by radix-2 stage launches only (cross-check) */
+#define ALOHA_FLAG_NTT_TWO_PASS 4u  /* N = 2^12, 2^13 through the two-pass tile kernels too (default: single pass) */
+#define ALOHA_FLAG_NTT_SINGLE_14 8u /* N = 2^14 through the single-pass kernel as well (default: two passes)        */
 
 /* ---- lifecycle ----------------------------------------------------------------------- */
 aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out);

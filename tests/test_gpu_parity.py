@@ -137,6 +137,28 @@ def test_ntt_worst_case_ranges(engine):
         assert np.array_equal(back, pats % np.uint64(q))
 
 
+@pytest.mark.parametrize("logn", [12, 13, 14])
+def test_single_pass_and_two_pass_forms_agree(logn):
+    """N = 2^12..2^14 exist in two kernel forms (one pass through LDS, two passes of tiles): both against
+    the oracle, both directions, several bundle shapes, in and out of place, worst-case ranges."""
+    n, rows = 1 << logn, (1 << logn) // 128
+    rng = np.random.default_rng(900 + logn)
+    mods = [oracle.nth_prime(logn, i) for i in (0, 0, 0, 0, 0, 1, 1, 2)] + [Q0 if logn == 13 else oracle.nth_prime(logn, 3)]
+    data = np.stack([residues(rng, n, q) for q in mods])
+    data[0, :] = np.uint64((1 << 60) - 1)                          # non-canonical maximum (< 2q): widest lazy ranges
+    data[1, ::2] = 0
+    exp = np.stack([oracle.ntt(d % np.uint64(q), q) for d, q in zip(data, mods)])   # memory words < 2q mean d mod q
+    for flags in (avp.FLAG_NTT_TWO_PASS, avp.FLAG_NTT_SINGLE_14):
+        with avp.VP(spm_rows=4 * len(mods) * rows, ksk_rows=1, max_log_n=14, flags=flags) as vp:
+            vp.write(SPM, 0, data.reshape(-1))
+            vp.ntt_rows(SPM, len(mods) * rows, 0, logn, mods)                      # out of place
+            f = vp.read(SPM, len(mods) * rows, len(mods) * n).reshape(len(mods), n)
+            assert np.array_equal(f, exp), flags
+            vp.ntt_rows(SPM, len(mods) * rows, len(mods) * rows, logn, mods, inverse=True)   # in place
+            back = vp.read(SPM, len(mods) * rows, len(mods) * n).reshape(len(mods), n)
+            assert np.array_equal(back, np.stack([d % np.uint64(q) for d, q in zip(data, mods)])), flags
+
+
 @pytest.mark.parametrize("logn", [10, 13, 16])
 def test_tile_kernels_agree_with_radix2_fallback(engine, engine_radix2, logn):
     rng = np.random.default_rng(300 + logn)

@@ -54,6 +54,28 @@ def config2():
     return out
 
 
+def small_n_batched():
+    """Batched transform rates at N = 2^12..2^15 (the reference's own size is 2^13), both directions."""
+    out = {}
+    for logn in (12, 13, 14, 15):
+        n = 1 << logn
+        B = (1 << 28) // (8 * n)                                 # 256 MiB of limbs
+        with avp.VP(spm_rows=B * n // 128, ksk_rows=1, max_log_n=logn) as vp:
+            mods = [avp.nth_prime(logn, i) for i in range(16) for _ in range(B // 16)]
+            rng = np.random.default_rng(logn)
+            a = rng.integers(0, mods[0], n, dtype=np.uint64)
+            vp.write(SPM, 0, a)
+            vp.ntt_rows(SPM, 0, 0, logn, mods)
+            assert np.array_equal(vp.read(SPM, 0, n), oracle.ntt(a, mods[0]))
+            vp.ntt_rows(SPM, 0, 0, logn, mods, inverse=True)
+            assert np.array_equal(vp.read(SPM, 0, n), a)
+            tf = timeit(lambda: vp.ntt_rows(SPM, 0, 0, logn, mods), vp.sync, 30)
+            ti = timeit(lambda: vp.ntt_rows(SPM, 0, 0, logn, mods, inverse=True), vp.sync, 30)
+            out[f"n{n}"] = {"limbs": B, "fwd_ntt_per_s": B / tf, "fwd_algorithmic_GBps": 16 * n * B / tf / 1e9,
+                            "inv_ntt_per_s": B / ti, "inv_algorithmic_GBps": 16 * n * B / ti / 1e9}
+    return out
+
+
 def config3():
     logn, n, L = 14, 1 << 14, 8
     rows = n // 128
@@ -155,7 +177,7 @@ def aut_batch():
 
 
 if __name__ == "__main__":
-    todo = {"config2_ntt_n4096": config2, "config3_polymul_n16384_8limbs": config3,
+    todo = {"config2_ntt_n4096": config2, "small_n_batched": small_n_batched, "config3_polymul_n16384_8limbs": config3,
             "config4_keyswitch_n65536_L24": lambda: config45(24), "config5_keyswitch_n65536_L32": lambda: config45(32),
             "config5_automorphism_batch": aut_batch,
             "hybrid_config4_L24_alpha4": lambda: hybrid45(24, 4), "hybrid_config5_L32_alpha4": lambda: hybrid45(32, 4),
