@@ -154,33 +154,7 @@ template <bool UNI>
 ALOHA_DEV u64 shoup_fold_add(u64 X, u64 a, u64 w, u64 qhat, u64 nq) {
   u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(w), w1 = hi32(w);
   u32 b0 = lo32(qhat), b1 = hi32(qhat), n0 = lo32(nq), n1 = hi32(nq);
-#if ALOHA_FOLD_CHAIN == 2
-  // the six multiply-adds as ONE statement (no inter-statement padding), the two chains interleaved
-  u64 t, acc;
-  if (UNI)
-    asm("v_mad_u64_u32 %0, s[94:95], %3, %5, 0\n\t"
-        "v_mad_u64_u32 %1, s[94:95], %2, %4, %10\n\t"
-        "v_mad_u64_u32 %0, s[94:95], %2, %5, %0\n\t"
-        "v_mad_u64_u32 %1, s[94:95], %6, %8, %1\n\t"
-        "v_mad_u64_u32 %0, s[94:95], %7, %8, %0\n\t"
-        "v_mad_u64_u32 %0, s[94:95], %6, %9, %0"
-        : "=&v"(t), "=&v"(acc)
-        : "v"(a0), "v"(a1), "s"(w0), "s"(w1), "v"(b0), "v"(b1), "s"(n0), "s"(n1), "v"(X)
-        : "s94", "s95");
-  else
-    asm("v_mad_u64_u32 %0, s[94:95], %3, %5, 0\n\t"
-        "v_mad_u64_u32 %1, s[94:95], %2, %4, %10\n\t"
-        "v_mad_u64_u32 %0, s[94:95], %2, %5, %0\n\t"
-        "v_mad_u64_u32 %1, s[94:95], %6, %8, %1\n\t"
-        "v_mad_u64_u32 %0, s[94:95], %7, %8, %0\n\t"
-        "v_mad_u64_u32 %0, s[94:95], %6, %9, %0"
-        : "=&v"(t), "=&v"(acc)
-        : "v"(a0), "v"(a1), "v"(w0), "v"(w1), "v"(b0), "v"(b1), "s"(n0), "s"(n1), "v"(X)
-        : "s94", "s95");
-  u32 h = hi32(acc);
-  asm("v_add_u32 %0, %0, %1" : "+v"(h) : "v"(lo32(t)));
-  return pack64(lo32(acc), h);
-#elif ALOHA_FOLD_CHAIN
+#if ALOHA_FOLD_CHAIN
   u64 t = UNI ? mad32_zs(a1, w0) : mad32_z(a1, w0);
   t = UNI ? mad32_s(a0, w1, t) : mad32(a0, w1, t);
   t = mad32_s(b1, n0, t);

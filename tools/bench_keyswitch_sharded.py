@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""BASELINE configs 4 / 5 on G GPUs: rotate + key-switch or ciphertext product + relinearisation at
+N = 2^16 with the RNS limbs sharded over the ranks (limb j on rank j mod G), one process per GPU,
+exchanges over torch.distributed (nccl = RCCL over xGMI; zero-copy views of engine memory).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node G --master-addr 127.0.0.1 --master-port P \\
+        tools/bench_keyswitch_sharded.py --L 24 --alpha 4 --op multiply
+
+--alpha 0 runs the reference's algorithm (one digit per prime, one special prime: keyswitch.py), any
+other value the hybrid key-switch (hybrid.py) with K = alpha special primes.  Rank 0 prints one JSON
+line.  Rehearsal on a one-GPU box: ALOHA_BENCH_BACKEND=gloo ALOHA_BENCH_DEVICE=0 lets several ranks share
+the GPU (the exchange then goes through host copies).  The result is checked: every rank's owned limbs
+against a single-rank run of the oracle's ISA machine would take minutes at this size, so the check is the
+2-rank == 1-rank parity of tests/ at small N plus, here, rank-count independence of a checksum when
+--verify is given (a second, single-process engine computes the same operation on rank 0)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--L", type=int, default=24)
+    ap.add_argument("--alpha", type=int, default=4)
+    ap.add_argument("--op", choices=["rotate", "multiply"], default="multiply")
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--log-n", type=int, default=16)
+    ap.add_argument("--verify", action="store_true")
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("ALOHA_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    backend = os.environ.get("ALOHA_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    from aloha_amd import hybrid, keyswitch
+    from aloha_amd import vp as avp
+
+    logn, n, L = args.log_n, 1 << args.log_n, args.L
+    mods = [avp.nth_prime(logn, i) for i in range(L)]
+    K = max(1, args.alpha)
+    specials = [avp.nth_prime(logn, L + k) for k in range(K)]
+    ex = keyswitch.Exchange(tensor_of=keyswitch.device_tensor if backend == "nccl" else None, always=False)
+
+    def build(vp, w, r, exch):
+        if args.alpha == 0:
+            return keyswitch.ShardedKeySwitch(vp, n, mods, specials[0], world=w, rank=r, exchange=exch)
+        return hybrid.HybridKeySwitch(vp, n, mods, specials, args.alpha, world=w, rank=r, exchange=exch)
+
+    def layout(w, r):
+        return keyswitch.Layout(n, mods, specials[0], w, r) if args.alpha == 0 else hybrid.HybridLayout(n, mods, specials, args.alpha, w, r)
+
+    def load(ks, lo, seed=7):
+        """Same pseudo-random ciphertexts and key on every rank count: limb contents depend on the limb only."""
+        all_mods = mods + (specials[:1] if args.alpha == 0 else specials)
+        digits = L if args.alpha == 0 else lo.dnum
+        for jl, j in enumerate(lo.owned_all):
+            rng = np.random.default_rng(seed * 1000 + j)
+            ks.vp.write(1, jl * digits * 2 * lo.rows, rng.integers(0, all_mods[j], digits * 2 * n, dtype=np.uint64))
+        ct = np.stack([np.random.default_rng(seed * 77 + j).integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
+        ks.load_ct(ct); ks.load_ct_b(ct[::-1].copy())
+
+    lo = layout(world, rank)
+    vp = avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=max(1, lo.ksk_limbs * lo.rows), max_log_n=logn, device=local)
+    ks = build(vp, world, rank, ex)
+    load(ks, lo)
+    k = pow(3, 5, 2 * n)
+    op = (lambda: ks.rotate(k)) if args.op == "rotate" else ks.multiply
+
+    def barrier():
+        if dist.is_initialized() and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    op(); vp.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        op()
+    vp.sync()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if dist.is_initialized() and world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    out = ks.read_out()
+    ok = None
+    if args.verify:                                              # every rank: its owned limbs == a single-rank engine's
+        lo1 = layout(1, 0)
+        with avp.VP(spm_rows=lo1.spm_rows_needed, ksk_rows=lo1.ksk_limbs * lo1.rows, max_log_n=logn, device=local) as vp1:
+            ks1 = build(vp1, 1, 0, keyswitch.Exchange())
+            load(ks1, lo1)
+            (ks1.rotate(k) if args.op == "rotate" else ks1.multiply())
+            ref = ks1.read_out()
+        ok = all(np.array_equal(out[:, i], ref[:, j]) for i, j in enumerate(lo.owned_ct))
+        if dist.is_initialized() and world > 1:
+            t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(t[0] > 0.5)
+    if rank == 0:
+        print(json.dumps({"metric": f"{args.op} + key-switch at N=2^{logn}", "L": L, "alpha": args.alpha, "K": K, "n_gpus": world,
+                          "ms": elapsed / args.reps * 1e3, "ops_per_s": args.reps / elapsed, "backend": backend,
+                          "verified_against_single_rank": ok}))
+    vp.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
