@@ -61,6 +61,7 @@ def lib() -> C.CDLL:
         L.orc_intt.restype = None; L.orc_intt.argtypes = [p, C.c_uint, u64, p]
         L.orc_vaut.restype = None; L.orc_vaut.argtypes = [p, p, C.c_uint, u64, u64]
         L.orc_vautn.restype = None; L.orc_vautn.argtypes = [p, p, C.c_uint, u64]
+        L.orc_set_threads.restype = C.c_int; L.orc_set_threads.argtypes = [C.c_int]
         L.orc_vroli.restype = None; L.orc_vroli.argtypes = [p, p, C.c_uint, u64]
         L.orc_ntt_batch.restype = C.c_int; L.orc_ntt_batch.argtypes = [p, C.c_uint, u64, C.c_uint, C.c_int]
         L.orc_vp_create.restype = p; L.orc_vp_create.argtypes = [u64, u64]
@@ -126,6 +127,11 @@ def ntt(a, q, inverse=False):
 
 
 def intt(a, q): return ntt(a, q, inverse=True)
+
+
+def set_threads(n: int = 0) -> int:
+    """OpenMP threads used by batched ``ntt`` calls (limbs are independent); 0 = all cores."""
+    return int(lib().orc_set_threads(n))
 
 
 def vaut(a, q, k):

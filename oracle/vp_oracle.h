@@ -65,6 +65,7 @@ void orc_make_tables(uint64_t q, uint64_t psi, unsigned logn, uint64_t *tab, uin
 void orc_ntt(uint64_t *a, unsigned logn, uint64_t q, const uint64_t *tab);   /* vntt  */
 void orc_intt(uint64_t *a, unsigned logn, uint64_t q, const uint64_t *itab); /* vintt */
 void orc_vaut(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t q, uint64_t k);
+int orc_set_threads(int n);   /* OpenMP threads of orc_ntt_batch; 0 = all cores; returns the count in effect */
 void orc_vautn(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t k);   /* extension: NTT-domain automorphism */
 void orc_vroli(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t s);
 /* convenience: table build + transform of `count` limbs stored back to back */
