@@ -50,15 +50,27 @@ def test_op_list_parser_matches_fixture():
 @pytest.mark.reference
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="/root/reference not present")
 def test_run_oplist_tool_reproduces_every_rtl_dump(tmp_path):
-    """The reference's op list + its instruction ROM image, both unchanged, through the tool
-    (oracle engine on the CPU): every dump text-identical to tv/case2_16_16/rtl_result."""
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "run_oplist.py"), "--engine", "oracle",
-           "--oplist", os.path.join(REFERENCE, "vivado_prj/top_noaxilite.srcs/sources_1/imports/sim/model_run/case3.txt"),
-           "--tv", os.path.join(REFERENCE, "tv/case2_16_16"), "--out", str(tmp_path),
-           "--isram", os.path.join(REFERENCE, "sim/vp/isram_file_generator/isram_file.mem")]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "37 dumps written" in r.stdout and "0 differ" in r.stdout
+    """The reference's op list + its instruction ROM image, both unchanged, through the tool's flow
+    (with the oracle's machine as the engine, on the CPU): every dump text-identical to
+    tv/case2_16_16/rtl_result."""
+    import argparse
+    import contextlib
+    import importlib.util
+    import io
+    import oracle
+    spec = importlib.util.spec_from_file_location("run_oplist", os.path.join(ROOT, "tools", "run_oplist.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    args = argparse.Namespace(
+        oplist=os.path.join(REFERENCE, "vivado_prj/top_noaxilite.srcs/sources_1/imports/sim/model_run/case3.txt"),
+        tv=os.path.join(REFERENCE, "tv/case2_16_16"), out=str(tmp_path),
+        isram=os.path.join(REFERENCE, "sim/vp/isram_file_generator/isram_file.mem"))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = tool.run(oracle.OracleVP(), args)
+    out = buf.getvalue()
+    assert rc == 0, out[-2000:]
+    assert "37 dumps written" in out and "0 differ" in out
     final = open(tmp_path / "inst_28_out.txt").read().split()
     exp = open(os.path.join(REFERENCE, "vivado_prj/top_noaxilite.srcs/sources_1/new/case3_expected_result.txt")).read().split()
     assert final == exp

@@ -4,13 +4,14 @@ the test bench writes (``inst_K_out.txt``, ``inst_K_0_out.txt``), so they diff d
 ``tv/<case>/rtl_result``.
 
     python tools/run_oplist.py --oplist case3.txt --tv /path/to/tv/case2_16_16 --out outdir
-          [--isram isram_file.mem] [--engine gpu|oracle]
+          [--isram isram_file.mem]
 
 Inputs taken from the ``tv`` directory: the initial ciphertext (``rtl_result/inst_0_out.txt``),
-the encoder outputs (``rtl_result/inst_K_0_out.txt`` -- the CKKS encoder block itself is out of
-scope) and the keys ``ksk_step{2,4,8}.txt`` in the slot order of
-``load_ksk`` (top_noaxilite_tb.sv:372-394,:531).  Without ``--isram`` the own program
-generators are used.  ``--engine oracle`` runs the CPU oracle instead (test infrastructure).
+the RTL encoder's outputs (``rtl_result/inst_K_0_out.txt``: replaying the RTL chain bit for bit needs
+the RTL's own single-precision encoder results) and the keys
+``ksk_step{2,4,8}.txt`` in the slot order of ``load_ksk`` (top_noaxilite_tb.sv:372-394,:531).
+Without ``--isram`` the own program generators are used.  The command line always runs the GPU
+engine; ``run(vp, ...)`` takes any engine object (the tests pass the oracle's machine on the CPU).
 """
 from __future__ import annotations
 
@@ -34,15 +35,14 @@ def main() -> int:
     ap.add_argument("--tv", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--isram")
-    ap.add_argument("--engine", default="gpu", choices=["gpu", "oracle"])
     args = ap.parse_args()
+    from aloha_amd import vp as avp
+    with avp.VP(spm_rows=1 << 16, ksk_rows=1 << 16, max_log_n=13) as vp:
+        return run(vp, args)
 
-    if args.engine == "gpu":
-        from aloha_amd import vp as avp
-        vp = avp.VP(spm_rows=1 << 16, ksk_rows=1 << 16, max_log_n=13)
-    else:
-        import oracle
-        vp = oracle.OracleVP()
+
+def run(vp, args) -> int:
+    """``args``: an object with ``oplist``, ``tv``, ``out`` and ``isram`` (or None)."""
     tb = harness.TestBench(vp)
     if args.isram:
         vp.load_isram(0, isa.parse_mem_text(open(args.isram).read()))
