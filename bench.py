@@ -119,7 +119,7 @@ def main() -> int:
         local_rank = int(os.environ["ALOHA_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ALOHA_BENCH_FORCE_DIST"):      # (the knob exercises the RCCL path with one rank)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
