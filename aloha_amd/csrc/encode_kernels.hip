@@ -114,7 +114,52 @@ __global__ __launch_bounds__(256) void encode_finish_kernel(const cplx *__restri
   }
 }
 
+// ---- decode: the inverse map, from one coefficient-form limb per plaintext ---------------------------
+// u_i = c_i + i*c_{i+n} (centred lifts), x_i = u_i * zeta^i, y = IFFT_n(x) * n / Delta, slots from y by the same
+// map.  IFFT(x) = conj(FFT(conj(x))) / n, so the stage kernel of the encoder is reused unchanged:
+// work[p] = conj(x_{brv(p)}), log2 n radix-2 stages in HBM (off the hot path), then conj / Delta and the scatter.
+__device__ __forceinline__ double centred_lift(u64 v, u64 q) {
+  v = v >= q ? v - q : v;                                   // memory words are < 2q
+  return v > (q >> 1) ? -(double)(q - v) : (double)v;
+}
+
+__global__ __launch_bounds__(256) void decode_prep_kernel(const u64 *__restrict__ limbs, size_t limb_stride, EncodeTables tb,
+                                                          cplx *__restrict__ work, u64 q, unsigned log_slots) {
+  const uint32_t n = 1u << log_slots, p = blockIdx.x * 256 + threadIdx.x, plain = blockIdx.y;
+  const uint32_t i = bitrev32(p, log_slots);
+  const u64 *limb = limbs + (size_t)plain * limb_stride;
+  const cplx u{centred_lift(limb[i], q), centred_lift(limb[i + n], q)};
+  const cplx tw = reinterpret_cast<const cplx *>(tb.twist)[i];            // zeta^-i; zeta^i is its conjugate
+  const cplx x = cmul(u, cplx{tw.x, -tw.y});
+  work[(size_t)plain * n + p] = cplx{x.x, -x.y};
+}
+
+__global__ __launch_bounds__(256) void decode_finish_kernel(const cplx *__restrict__ work, EncodeTables tb,
+                                                            double *__restrict__ out, unsigned log_slots, double inv_scale) {
+  const uint32_t n = 1u << log_slots, t = blockIdx.x * 256 + threadIdx.x, plain = blockIdx.y;
+  const cplx r = work[(size_t)plain * n + t];
+  const uint32_t e = tb.src[t], j = e & 0x7fffffffu;
+  const double re = r.x * inv_scale, im = -r.y * inv_scale;               // y_t = conj(R_t) / Delta
+  double *z = out + (size_t)plain * 2 * n;
+  z[2 * j] = re;
+  z[2 * j + 1] = (e >> 31) ? -im : im;
+}
+
 }  // namespace
+
+hipError_t decode(hipStream_t st, const u64 *d_limbs, size_t limb_stride_words, const EncodeTables &tb, void *d_work,
+                  double *d_out, u64 q, uint32_t nplain, unsigned logn, double scale, uint64_t *launches) {
+  if (logn < 10 || logn > 16 || !nplain || !d_work) return hipErrorInvalidValue;
+  const unsigned log_slots = logn - 1;
+  const uint32_t n = 1u << log_slots;
+  cplx *work = reinterpret_cast<cplx *>(d_work);
+  hipLaunchKernelGGL(decode_prep_kernel, dim3(n / 256, nplain), dim3(256), 0, st, d_limbs, limb_stride_words, tb, work, q, log_slots);
+  for (unsigned ls = 1; ls <= log_slots; ls++)
+    hipLaunchKernelGGL(encode_stage_kernel, dim3(n / 2 / 256, nplain), dim3(256), 0, st, work, tb, log_slots, ls);
+  hipLaunchKernelGGL(decode_finish_kernel, dim3(n / 256, nplain), dim3(256), 0, st, work, tb, d_out, log_slots, 1.0 / scale);
+  if (launches) *launches += log_slots + 2;
+  return hipGetLastError();
+}
 
 hipError_t encode(hipStream_t st, const double *d_re_im, const EncodeTables &tb, void *d_work, u64 *d_out,
                   const u64 *d_moduli, uint32_t nlimbs, uint32_t nplain, unsigned logn, double scale,

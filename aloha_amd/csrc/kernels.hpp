@@ -139,5 +139,10 @@ hipError_t encode(hipStream_t st, const double *d_re_im, const EncodeTables &tb,
                   const u64 *d_moduli, uint32_t nlimbs, uint32_t nplain, unsigned logn, double scale,
                   uint64_t *launches);
 
+// the inverse map: one coefficient-form limb (modulus q) per plaintext, `limb_stride_words` apart, -> nplain * N
+// doubles (slots, (re, im) interleaved) at d_out; d_work: nplain * n complex doubles
+hipError_t decode(hipStream_t st, const u64 *d_limbs, size_t limb_stride_words, const EncodeTables &tb, void *d_work,
+                  double *d_out, u64 q, uint32_t nplain, unsigned logn, double scale, uint64_t *launches);
+
 }  // namespace k
 }  // namespace aloha

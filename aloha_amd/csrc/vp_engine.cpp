@@ -986,19 +986,12 @@ aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64
   return run_transforms(vp, jobs, log_n, inverse != 0);
 }
 
-// CKKS encoder block: see encode_kernels.hip / include/aloha_vp.h.  Tables for ring size N (n = N/2):
-// w[k] = exp(-2 pi i k / n), twist[k] = exp(-i pi k / N) in long double, and the slot map of the
-// rotation group generated by 3 (run_rotate's k = 3^step, top_noaxilite_tb.sv:531).
-aloha_status aloha_vp_encode(aloha_vp *vp, int space, uint64_t dst_row, const double *host_re_im, uint32_t nplain,
-                             uint32_t log_n, const uint64_t *moduli, uint32_t nlimbs, double scale) {
-  if (!vp || !host_re_im || !moduli || !nplain || !nlimbs || !(scale > 0)) return ALOHA_ERR_ARG;
-  if (log_n < 10 || log_n > 16) return fail(vp, ALOHA_ERR_VL, "encode: log_n = %u", log_n);
-  for (uint32_t l = 0; l < nlimbs; l++)
-    if (!modulus_ok(moduli[l])) return fail(vp, ALOHA_ERR_MODULUS, "encode: modulus[%u] = %#llx", l, (u64)moduli[l]);
+}  // extern "C" (closed for two file-local helpers)
+
+// Tables of the encoder block for ring size N = 2^log_n (n = N/2): w[k] = exp(-2 pi i k / n),
+// twist[k] = exp(-i pi k / N) in long double, and the slot map of the rotation group generated by 3.
+static aloha_status enc_tables_for(aloha_vp *vp, uint32_t log_n, const aloha::k::EncodeTables **out) {
   const size_t N = (size_t)1 << log_n, n = N / 2;
-  const uint64_t bytes = (uint64_t)nplain * nlimbs * N * 8;
-  u64 *dst = space_ptr(vp, space, dst_row, bytes);
-  if (!dst) return fail(vp, ALOHA_ERR_ADDR, "encode: %u x %u limbs at row %llu outside space %d", nplain, nlimbs, (u64)dst_row, space);
   auto it = vp->enc_tables.find(log_n);
   if (it == vp->enc_tables.end()) {
     std::vector<double> host(n + 2 * n + n / 2 + 8);        // w (n/2 complex) | twist (n complex) | src (n u32)
@@ -1028,32 +1021,77 @@ aloha_status aloha_vp_encode(aloha_vp *vp, int space, uint64_t dst_row, const do
     tab.t.src = reinterpret_cast<const uint32_t *>(tab.t.twist + 2 * n);
     it = vp->enc_tables.emplace(log_n, tab).first;
   }
+  *out = &it->second.t;
+  return ALOHA_OK;
+}
+
+static aloha_status grow(aloha_vp *vp, void **buf, size_t *have, size_t need) {
+  if (need <= *have) return ALOHA_OK;
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr; *have = 0;
+  HIPCK(vp, hipMalloc(buf, need));
+  *have = need;
+  return ALOHA_OK;
+}
+
+extern "C" {
+
+// CKKS encoder block: see encode_kernels.hip / include/aloha_vp.h.  Tables for ring size N (n = N/2):
+// w[k] = exp(-2 pi i k / n), twist[k] = exp(-i pi k / N) in long double, and the slot map of the
+// rotation group generated by 3 (run_rotate's k = 3^step, top_noaxilite_tb.sv:531).
+aloha_status aloha_vp_encode(aloha_vp *vp, int space, uint64_t dst_row, const double *host_re_im, uint32_t nplain,
+                             uint32_t log_n, const uint64_t *moduli, uint32_t nlimbs, double scale) {
+  if (!vp || !host_re_im || !moduli || !nplain || !nlimbs || !(scale > 0)) return ALOHA_ERR_ARG;
+  if (log_n < 10 || log_n > 16) return fail(vp, ALOHA_ERR_VL, "encode: log_n = %u", log_n);
+  for (uint32_t l = 0; l < nlimbs; l++)
+    if (!modulus_ok(moduli[l])) return fail(vp, ALOHA_ERR_MODULUS, "encode: modulus[%u] = %#llx", l, (u64)moduli[l]);
+  const size_t N = (size_t)1 << log_n, n = N / 2;
+  const uint64_t bytes = (uint64_t)nplain * nlimbs * N * 8;
+  u64 *dst = space_ptr(vp, space, dst_row, bytes);
+  if (!dst) return fail(vp, ALOHA_ERR_ADDR, "encode: %u x %u limbs at row %llu outside space %d", nplain, nlimbs, (u64)dst_row, space);
+  const aloha::k::EncodeTables *tabs = nullptr;
+  { aloha_status ts = enc_tables_for(vp, log_n, &tabs); if (ts) return ts; }
   const size_t in_bytes = (size_t)nplain * N * 8, work_bytes = log_n > 14 ? (size_t)nplain * n * 16 : 0;
-  if (in_bytes > vp->enc_in_bytes) {
-    HIPCK(vp, hipStreamSynchronize(vp->stream));
-    if (vp->d_enc_in) (void)hipFree(vp->d_enc_in);
-    vp->d_enc_in = nullptr; vp->enc_in_bytes = 0;
-    HIPCK(vp, hipMalloc(&vp->d_enc_in, in_bytes));
-    vp->enc_in_bytes = in_bytes;
-  }
-  if (work_bytes > vp->enc_work_bytes) {
-    HIPCK(vp, hipStreamSynchronize(vp->stream));
-    if (vp->d_enc_work) (void)hipFree(vp->d_enc_work);
-    vp->d_enc_work = nullptr; vp->enc_work_bytes = 0;
-    HIPCK(vp, hipMalloc(&vp->d_enc_work, work_bytes));
-    vp->enc_work_bytes = work_bytes;
-  }
+  { aloha_status gs = grow(vp, &vp->d_enc_in, &vp->enc_in_bytes, in_bytes); if (gs) return gs; }
+  { aloha_status gs = grow(vp, &vp->d_enc_work, &vp->enc_work_bytes, work_bytes); if (gs) return gs; }
   const void *d_moduli = nullptr;
   aloha_status s = device_blob(vp, moduli, (size_t)nlimbs * 8, &d_moduli);
   if (s) return s;
   HIPCK(vp, hipMemcpyAsync(vp->d_enc_in, host_re_im, in_bytes, hipMemcpyHostToDevice, vp->stream));
   uint64_t launches = 0;
-  hipError_t e = aloha::k::encode(vp->stream, reinterpret_cast<const double *>(vp->d_enc_in), it->second.t,
+  hipError_t e = aloha::k::encode(vp->stream, reinterpret_cast<const double *>(vp->d_enc_in), *tabs,
                                   vp->d_enc_work, dst, reinterpret_cast<const u64 *>(d_moduli), nlimbs, nplain, log_n,
                                   scale, &launches);
   vp->stats.kernel_launches += launches;
   if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "encode launch failed: %s", hipGetErrorString(e));
   HIPCK(vp, hipStreamSynchronize(vp->stream));         // the host buffer is borrowed for the call only
+  return ALOHA_OK;
+}
+
+// The inverse of aloha_vp_encode from ONE coefficient-form limb per plaintext (the reference has no
+// decoder block; this closes the loop for users and tests).
+aloha_status aloha_vp_decode(aloha_vp *vp, int space, uint64_t src_row, uint64_t limb_stride, double *host_re_im,
+                             uint32_t nplain, uint32_t log_n, uint64_t modulus, double scale) {
+  if (!vp || !host_re_im || !nplain || !(scale > 0)) return ALOHA_ERR_ARG;
+  if (log_n < 10 || log_n > 16) return fail(vp, ALOHA_ERR_VL, "decode: log_n = %u", log_n);
+  if (!modulus_ok(modulus)) return fail(vp, ALOHA_ERR_MODULUS, "decode: modulus = %#llx", (u64)modulus);
+  const size_t N = (size_t)1 << log_n, n = N / 2;
+  if (limb_stride == 0 && nplain > 1) return ALOHA_ERR_ARG;
+  const uint64_t span = ((uint64_t)(nplain - 1) * limb_stride + 1) * N * 8;
+  const u64 *src = space_ptr(vp, space, src_row, span);
+  if (!src) return fail(vp, ALOHA_ERR_ADDR, "decode: %u limbs (stride %llu) at row %llu outside space %d", nplain, (u64)limb_stride, (u64)src_row, space);
+  const aloha::k::EncodeTables *tabs = nullptr;
+  { aloha_status ts = enc_tables_for(vp, log_n, &tabs); if (ts) return ts; }
+  { aloha_status gs = grow(vp, &vp->d_enc_in, &vp->enc_in_bytes, (size_t)nplain * N * 8); if (gs) return gs; }
+  { aloha_status gs = grow(vp, &vp->d_enc_work, &vp->enc_work_bytes, (size_t)nplain * n * 16); if (gs) return gs; }
+  uint64_t launches = 0;
+  hipError_t e = aloha::k::decode(vp->stream, src, (size_t)limb_stride * N, *tabs, vp->d_enc_work,
+                                  reinterpret_cast<double *>(vp->d_enc_in), modulus, nplain, log_n, scale, &launches);
+  vp->stats.kernel_launches += launches;
+  if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "decode launch failed: %s", hipGetErrorString(e));
+  HIPCK(vp, hipMemcpyAsync(host_re_im, vp->d_enc_in, (size_t)nplain * N * 8, hipMemcpyDeviceToHost, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
   return ALOHA_OK;
 }
 

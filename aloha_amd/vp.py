@@ -37,7 +37,7 @@ EXPORTS = ["aloha_vp_abi_version", "aloha_status_string", "aloha_vp_create", "al
            "aloha_vp_last_error", "aloha_vp_write", "aloha_vp_read", "aloha_vp_device_ptr",
            "aloha_vp_load_isram", "aloha_vp_load_isram_hex", "aloha_vp_run", "aloha_vp_sync",
            "aloha_vp_ntt_rows", "aloha_find_psi", "aloha_nth_prime", "aloha_vp_get_stats",
-           "aloha_vp_peek_vreg", "aloha_vp_encode"]
+           "aloha_vp_peek_vreg", "aloha_vp_encode", "aloha_vp_decode"]
 
 
 class AlohaError(RuntimeError):
@@ -93,6 +93,7 @@ def load_library() -> C.CDLL:
     L.aloha_vp_get_stats.restype = i; L.aloha_vp_get_stats.argtypes = [p, C.POINTER(_Stats)]
     L.aloha_vp_peek_vreg.restype = i; L.aloha_vp_peek_vreg.argtypes = [p, u32, p, u64]
     L.aloha_vp_encode.restype = i; L.aloha_vp_encode.argtypes = [p, i, u64, p, u32, u32, p, u32, C.c_double]
+    L.aloha_vp_decode.restype = i; L.aloha_vp_decode.argtypes = [p, i, u64, u64, p, u32, u32, u64, C.c_double]
     _lib = L
     return L
 
@@ -199,6 +200,14 @@ class VP:
         m = np.ascontiguousarray(moduli, dtype=np.uint64)
         self._chk(self._L.aloha_vp_encode(self._h, space, dst_row, z.ctypes.data, z.shape[0], log_n,
                                           m.ctypes.data, m.size, float(scale)))
+
+    def decode(self, space: int, src_row: int, log_n: int, modulus: int, nplain: int = 1, limb_stride: int = 1,
+               scale: float = 2.0 ** 38) -> np.ndarray:
+        """Slots ((re, im) interleaved, N doubles per plaintext) from one coefficient-form limb per plaintext."""
+        out = np.empty((nplain, 1 << log_n), dtype=np.float64)
+        self._chk(self._L.aloha_vp_decode(self._h, space, src_row, limb_stride, out.ctypes.data, nplain, log_n,
+                                          modulus, float(scale)))
+        return out
 
     # -- introspection ------------------------------------------------------------------------
     def stats(self) -> dict:

@@ -126,6 +126,12 @@ aloha_status aloha_vp_encode(aloha_vp *vp, int space, uint64_t dst_row, const do
                              uint32_t nplain, uint32_t log_n, const uint64_t *moduli, uint32_t nlimbs,
                              double scale);
 
+/* The inverse map (no counterpart in the reference, which has an encoder only): nplain plaintexts, each given
+ * by ONE coefficient-form limb under `modulus` (plaintext p at src_row + p*limb_stride*(N/128); valid while every
+ * coefficient's centred value is below modulus/2), to nplain * N doubles (slots, (re, im) interleaved). */
+aloha_status aloha_vp_decode(aloha_vp *vp, int space, uint64_t src_row, uint64_t limb_stride, double *host_re_im,
+                             uint32_t nplain, uint32_t log_n, uint64_t modulus, double scale);
+
 /* ---- parameters ------------------------------------------------------------------------------ */
 /* minimal primitive 2N-th root of unity mod q -- the rule behind the reference's hard-coded
  * psi values (tf_rom_generator.sv:75) */

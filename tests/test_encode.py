@@ -74,6 +74,21 @@ def test_encode_is_an_embedding_round_trip():
         e = e * 3 % (2 * Nn)
 
 
+def test_oracle_decode_inverts_encode_and_reads_the_golden_plaintexts():
+    """decode(encode(z)) = z to rounding (|coefficient error| <= 1/2 spread over n slots / 2^38), and the
+    golden model plaintexts decode to their 6-digit cleartexts."""
+    rng = np.random.default_rng(11)
+    for logn in (10, 13):
+        z = rng.uniform(-1, 1, 1 << logn)
+        back = ce.decode(ce.encode(z, logn, [Q0])[0], logn, Q0)
+        assert np.abs(back - z).max() < 1e-7
+    for key in ENC_KEYS:
+        ent = manifest()["encode"][key]
+        z = cleartext(ent["cleartext"])
+        back = ce.decode(load(ent["fft_mod"])[:N], 13, Q0)
+        assert np.abs(back - z).max() < 2e-6                            # six printed digits
+
+
 @pytest.mark.reference
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="/root/reference not present")
 def test_oracle_encode_full_tv_sweep():
@@ -157,6 +172,33 @@ def test_gpu_encode_then_encode_post_matches_model_plaintext(engine):
     back = engine.read(avp.SPM, 0x200, 2 * N).reshape(2, N)
     check_against_fft_mod(back, back_gold)
     assert np.array_equal(np.stack([oracle.intt(ntt_form[:N], Q0), oracle.intt(ntt_form[N:], Q1)]), back)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logn", [10, 12, 13, 14, 16])
+def test_gpu_decode_matches_oracle_and_inverts_encode(engine, logn):
+    """Tolerance: 1e-9 absolute against the oracle on slots of magnitude <= 1 (same arithmetic, different
+    summation order); the round trip returns the cleartext to 1e-7 (coefficient rounding at scale 2^38)."""
+    from aloha_amd import vp as avp
+    n = 1 << logn
+    rng = np.random.default_rng(200 + logn)
+    q = avp.nth_prime(logn, 0)
+    z = rng.uniform(-1, 1, (3, n))
+    engine.encode(avp.SPM, 0, z, logn, [q, avp.nth_prime(logn, 1)])       # 2 limbs per plaintext: stride 2
+    got = engine.decode(avp.SPM, 0, logn, q, nplain=3, limb_stride=2)
+    limbs = engine.read(avp.SPM, 0, 6 * n).reshape(3, 2, n)
+    for p in range(3):
+        assert np.abs(got[p] - ce.decode(limbs[p, 0], logn, q)).max() < 1e-9
+        assert np.abs(got[p] - z[p]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_gpu_decode_reads_the_golden_plaintext(engine):
+    from aloha_amd import vp as avp
+    ent = manifest()["encode"]["case2/kernel13"]
+    engine.write(avp.SPM, 0, load(ent["fft_mod"]))
+    got = engine.decode(avp.SPM, 0, 13, Q0)[0]
+    assert np.abs(got - cleartext(ent["cleartext"])).max() < 2e-6
 
 
 @pytest.mark.gpu
