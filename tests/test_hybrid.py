@@ -86,6 +86,48 @@ def test_hybrid_rotate_and_multiply_decrypt_correctly(alpha, K):
     assert max(abs(a - b) for a, b in zip(got, exp)) < 1 << 36 and max(abs(x) for x in exp) > 1 << 50
 
 
+class _RomOnly:
+    """Engine stand-in that only accepts instruction images (program generation needs nothing else)."""
+    def __init__(self):
+        self.images = []
+
+    def load_isram(self, pc, words):
+        assert pc + len(words) <= 4096
+        self.images.append((pc, len(words)))
+
+
+@pytest.mark.parametrize("L,alpha,world", [(24, 4, 1), (32, 4, 1), (24, 8, 1), (24, 4, 8), (32, 4, 8), (24, 1, 1), (13, 3, 4)])
+def test_programs_fit_the_rom_and_layouts_partition(L, alpha, world):
+    """BASELINE configs 4/5 shapes: every generated program fits the 4096-word instruction ROM, every
+    modulus and gather slot is owned exactly once, and the transform count is dnum*(L+K) - L + 3L + 2K."""
+    from aloha_amd import isa
+    n, K = 1 << 16, alpha
+    mods = [oracle.nth_prime(16, i) for i in range(L)]
+    specials = [oracle.nth_prime(16, L + k) for k in range(K)]
+    owned, yslots, wslots, ntt, intt = [], set(), set(), 0, 0
+    for r in range(world):
+        hs = hybrid.HybridKeySwitch(_RomOnly(), n, mods, specials, alpha, world=world, rank=r)
+        lo = hs.lo
+        owned += lo.owned_all
+        for name, progs in hs._p.items():
+            for w in progs:
+                assert len(w) <= isa.IRAM_DEPTH
+                if name in ("rot1", "mid", "terms", "fin_rot"):
+                    for ins in isa.insts_of(w):
+                        ntt += ins.name == "vntt"
+                        intt += ins.name == "vintt"
+        for i in lo.owned_ct:
+            yslots.add(lo.y_slot(i) - lo.y)
+        for k in lo.owned_sp:
+            wslots.update({lo.w_slot(k, 0) - lo.w, lo.w_slot(k, 1) - lo.w})
+        assert lo.spm_rows_needed == lo.slots * 512
+    dnum = -(-L // alpha)
+    assert sorted(owned) == list(range(L + K))
+    assert len(yslots) == L and max(yslots) < world * -(-L // world)
+    assert len(wslots) == 2 * K
+    assert intt == L + 2 * K and ntt == dnum * (L + K) - L + 2 * L
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
