@@ -180,9 +180,14 @@ __global__ __launch_bounds__(256) void dot_kernel(DotArgs g, uint32_t n2) {
     }
     for (int t = 0; t < g.nterms; t++) {
       const u64x2 va = reinterpret_cast<const u64x2 *>(g.a[t])[i];
-      const u64x2 vb = g.b[t] ? reinterpret_cast<const u64x2 *>(g.b[t])[i] : u64x2{g.s[t], g.s[t]};   // (s is normalised)
-      acc.x = addmod(acc.x, mulmod_barrett(csub(va.x, q), csub(vb.x, q), q, mu), q);
-      acc.y = addmod(acc.y, mulmod_barrett(csub(va.y, q), csub(vb.y, q), q, mu), q);
+      if (g.b[t]) {
+        const u64x2 vb = reinterpret_cast<const u64x2 *>(g.b[t])[i];
+        acc.x = addmod(acc.x, mulmod_barrett(csub(va.x, q), csub(vb.x, q), q, mu), q);
+        acc.y = addmod(acc.y, mulmod_barrett(csub(va.y, q), csub(vb.y, q), q, mu), q);
+      } else {                                               // scalar term: Shoup product (any 64-bit input, result < 2q)
+        acc.x = addmod(acc.x, csub(mul_shoup_2q(va.x, g.s[t], g.sp[t], q), q), q);
+        acc.y = addmod(acc.y, csub(mul_shoup_2q(va.y, g.s[t], g.sp[t], q), q), q);
+      }
     }
     reinterpret_cast<u64x2 *>(g.d)[i] = acc;
   }
@@ -198,23 +203,25 @@ __global__ __launch_bounds__(256) void dot_batch_kernel(const DotArgs *__restric
       acc = reinterpret_cast<const u64x2 *>(g->init)[i];
       acc.x = csub(acc.x, q); acc.y = csub(acc.y, q);
     }
-    auto second = [&](int t) -> u64x2 {                      // vector operand, or the scalar of a vfqmul.vs term (uniform branch)
-      return g->b[t] ? reinterpret_cast<const u64x2 *>(g->b[t])[i] : u64x2{g->s[t], g->s[t]};
+    auto term = [&](int t, const u64x2 &a) {                 // acc += a .* (vector operand | scalar of a vfqmul.vs term)
+      if (g->b[t]) {                                         // (uniform branch: the job descriptor is wave-uniform)
+        const u64x2 b = reinterpret_cast<const u64x2 *>(g->b[t])[i];
+        acc.x = addmod(acc.x, mulmod_barrett(csub(a.x, q), csub(b.x, q), q, mu), q);
+        acc.y = addmod(acc.y, mulmod_barrett(csub(a.y, q), csub(b.y, q), q, mu), q);
+      } else {
+        const u64 s = g->s[t], sp = g->sp[t];
+        acc.x = addmod(acc.x, csub(mul_shoup_2q(a.x, s, sp, q), q), q);
+        acc.y = addmod(acc.y, csub(mul_shoup_2q(a.y, s, sp, q), q), q);
+      }
     };
     int t = 0;
-    for (; t + 1 < nterms; t += 2) {                         // two terms per trip: four 16-byte loads in flight
-      const u64x2 a0 = reinterpret_cast<const u64x2 *>(g->a[t])[i], b0 = second(t);
-      const u64x2 a1 = reinterpret_cast<const u64x2 *>(g->a[t + 1])[i], b1 = second(t + 1);
-      acc.x = addmod(acc.x, mulmod_barrett(csub(a0.x, q), csub(b0.x, q), q, mu), q);
-      acc.y = addmod(acc.y, mulmod_barrett(csub(a0.y, q), csub(b0.y, q), q, mu), q);
-      acc.x = addmod(acc.x, mulmod_barrett(csub(a1.x, q), csub(b1.x, q), q, mu), q);
-      acc.y = addmod(acc.y, mulmod_barrett(csub(a1.y, q), csub(b1.y, q), q, mu), q);
+    for (; t + 1 < nterms; t += 2) {                         // two terms per trip: their loads are in flight together
+      const u64x2 a0 = reinterpret_cast<const u64x2 *>(g->a[t])[i];
+      const u64x2 a1 = reinterpret_cast<const u64x2 *>(g->a[t + 1])[i];
+      term(t, a0);
+      term(t + 1, a1);
     }
-    if (t < nterms) {
-      const u64x2 a0 = reinterpret_cast<const u64x2 *>(g->a[t])[i], b0 = second(t);
-      acc.x = addmod(acc.x, mulmod_barrett(csub(a0.x, q), csub(b0.x, q), q, mu), q);
-      acc.y = addmod(acc.y, mulmod_barrett(csub(a0.y, q), csub(b0.y, q), q, mu), q);
-    }
+    if (t < nterms) term(t, reinterpret_cast<const u64x2 *>(g->a[t])[i]);
     reinterpret_cast<u64x2 *>(g->d)[i] = acc;
   }
 }

@@ -59,7 +59,8 @@ constexpr int kDotTerms = 64;
 struct DotArgs {
   const u64 *a[kDotTerms];
   const u64 *b[kDotTerms];   // nullptr: term t is a[t] times the scalar s[t] (vfqmul.vs)
-  u64 s[kDotTerms];
+  u64 s[kDotTerms];          // normalised scalar (< q) ...
+  u64 sp[kDotTerms];         // ... and floor(s * 2^64 / q): scalar terms are Shoup products (14 instructions, Barrett: ~35)
   const u64 *init;         // may be null
   u64 *d;
   ModCtx m;

@@ -622,7 +622,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     for (size_t t0 = 0; t0 < lazy[r].size(); t0 += aloha::k::kDotTerms) {
       aloha::k::DotArgs g{};
       g.nterms = (int)std::min<size_t>(aloha::k::kDotTerms, lazy[r].size() - t0);
-      for (int t = 0; t < g.nterms; t++) { g.a[t] = lazy[r][t0 + t].first; g.b[t] = lazy[r][t0 + t].second; g.s[t] = lazy[r][t0 + t].s; }
+      for (int t = 0; t < g.nterms; t++) {
+        g.a[t] = lazy[r][t0 + t].first; g.b[t] = lazy[r][t0 + t].second; g.s[t] = lazy[r][t0 + t].s;
+        g.sp[t] = g.b[t] ? 0 : aloha::nt::shoup(g.s[t], lazy_q[r]);
+      }
       g.init = init; g.d = dst; g.m = modctx(lazy_q[r]);
       HIPCK(vp, aloha::k::dot(st, g, n));
       vp->stats.kernel_launches++;
@@ -911,7 +914,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
               if (!joinable()) ALOHA_RUN_CK(flush());
               aloha::k::DotArgs g{};
               g.nterms = (int)lazy[vs1].size();
-              for (int t = 0; t < g.nterms; t++) { g.a[t] = lazy[vs1][t].first; g.b[t] = lazy[vs1][t].second; g.s[t] = lazy[vs1][t].s; }
+              for (int t = 0; t < g.nterms; t++) {
+                g.a[t] = lazy[vs1][t].first; g.b[t] = lazy[vs1][t].second; g.s[t] = lazy[vs1][t].s;
+                g.sp[t] = g.b[t] ? 0 : aloha::nt::shoup(g.s[t], lazy_q[vs1]);
+              }
               g.init = nullptr; g.d = p; g.m = modctx(lazy_q[vs1]);
               dot_batch.push_back(g);
               auto grow = [&](const u64 *x, const u64 *&lo, const u64 *&hi) {
