@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void dot_kernel(DotArgs g, uint32_t n2) {
       acc.x = csub(acc.x, q); acc.y = csub(acc.y, q);
     }
     for (int t = 0; t < g.nterms; t++) {
+      if (!g.a[t]) { acc.x = addmod(acc.x, g.s[t], q); acc.y = addmod(acc.y, g.s[t], q); continue; }   // constant term
       const u64x2 va = reinterpret_cast<const u64x2 *>(g.a[t])[i];
       if (g.b[t]) {
         const u64x2 vb = reinterpret_cast<const u64x2 *>(g.b[t])[i];
@@ -203,8 +204,10 @@ __global__ __launch_bounds__(256) void dot_batch_kernel(const DotArgs *__restric
       acc = reinterpret_cast<const u64x2 *>(g->init)[i];
       acc.x = csub(acc.x, q); acc.y = csub(acc.y, q);
     }
-    auto term = [&](int t, const u64x2 &a) {                 // acc += a .* (vector operand | scalar of a vfqmul.vs term)
-      if (g->b[t]) {                                         // (uniform branch: the job descriptor is wave-uniform)
+    auto term = [&](int t, const u64x2 &a) {                 // acc += a .* (vector operand | scalar of a vfqmul.vs term) | constant
+      if (!g->a[t]) {
+        acc.x = addmod(acc.x, g->s[t], q); acc.y = addmod(acc.y, g->s[t], q);
+      } else if (g->b[t]) {                                         // (uniform branch: the job descriptor is wave-uniform)
         const u64x2 b = reinterpret_cast<const u64x2 *>(g->b[t])[i];
         acc.x = addmod(acc.x, mulmod_barrett(csub(a.x, q), csub(b.x, q), q, mu), q);
         acc.y = addmod(acc.y, mulmod_barrett(csub(a.y, q), csub(b.y, q), q, mu), q);
@@ -215,13 +218,13 @@ __global__ __launch_bounds__(256) void dot_batch_kernel(const DotArgs *__restric
       }
     };
     int t = 0;
+    auto first = [&](int t) -> u64x2 { return g->a[t] ? reinterpret_cast<const u64x2 *>(g->a[t])[i] : u64x2{0, 0}; };
     for (; t + 1 < nterms; t += 2) {                         // two terms per trip: their loads are in flight together
-      const u64x2 a0 = reinterpret_cast<const u64x2 *>(g->a[t])[i];
-      const u64x2 a1 = reinterpret_cast<const u64x2 *>(g->a[t + 1])[i];
+      const u64x2 a0 = first(t), a1 = first(t + 1);
       term(t, a0);
       term(t + 1, a1);
     }
-    if (t < nterms) term(t, reinterpret_cast<const u64x2 *>(g->a[t])[i]);
+    if (t < nterms) term(t, first(t));
     reinterpret_cast<u64x2 *>(g->d)[i] = acc;
   }
 }

@@ -57,7 +57,7 @@ hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsig
 // inner product (keyswitch.mem:46-79) as ONE pass over its operands.
 constexpr int kDotTerms = 64;
 struct DotArgs {
-  const u64 *a[kDotTerms];
+  const u64 *a[kDotTerms];   // nullptr: term t is the constant s[t]
   const u64 *b[kDotTerms];   // nullptr: term t is a[t] times the scalar s[t] (vfqmul.vs)
   u64 s[kDotTerms];          // normalised scalar (< q) ...
   u64 sp[kDotTerms];         // ... and floor(s * 2^64 / q): scalar terms are Shoup products (14 instructions, Barrett: ~35)

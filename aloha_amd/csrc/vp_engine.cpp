@@ -554,7 +554,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   unsigned batch_logn = 0;
   // Lazy dot products: register r stands for sum_t a_t .* b_t (mod lazy_q[r]) over memory
   // operands -- the key-switch inner product (keyswitch.mem:46-79) evaluated in one pass.
-  // (second == nullptr: the term is a_t times the scalar s, from vfqmul.vs)
+  // (second == nullptr: the term is a_t times the scalar s, from vfqmul.vs; first == nullptr too: the constant s)
   struct LazyTerm { const u64 *first, *second; u64 s; };
   std::vector<LazyTerm> lazy[ALOHA_NVREG];
   uint64_t lazy_q[ALOHA_NVREG] = {0};
@@ -624,7 +624,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       g.nterms = (int)std::min<size_t>(aloha::k::kDotTerms, lazy[r].size() - t0);
       for (int t = 0; t < g.nterms; t++) {
         g.a[t] = lazy[r][t0 + t].first; g.b[t] = lazy[r][t0 + t].second; g.s[t] = lazy[r][t0 + t].s;
-        g.sp[t] = g.b[t] ? 0 : aloha::nt::shoup(g.s[t], lazy_q[r]);
+        g.sp[t] = (g.b[t] || !g.a[t]) ? 0 : aloha::nt::shoup(g.s[t], lazy_q[r]);
       }
       g.init = init; g.d = dst; g.m = modctx(lazy_q[r]);
       HIPCK(vp, aloha::k::dot(st, g, n));
@@ -639,7 +639,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   auto before_mem_write = [&](const u64 *dst, size_t n, uint32_t next_pc) -> aloha_status {
     for (unsigned r = 0; r < ALOHA_NVREG; r++) {
       for (const auto &t : lazy[r])
-        if (overlap(t.first, dst, n) || (t.second && overlap(t.second, dst, n))) {
+        if ((t.first && overlap(t.first, dst, n)) || (t.second && overlap(t.second, dst, n))) {
           if (dead_from(vp, next_pc, r)) lazy[r].clear();
           else { aloha_status s = materialise(r, nullptr, (uint32_t)n); if (s) return s; }
           break;
@@ -691,7 +691,12 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     const bool fold_add = fuse && funct6 == 0x05 && funct3 == 0 && ((vs1 ^ vs2) & 1) && (vd == vs1 || vd == vs2) &&
                           !lazy[vs1].empty() && !lazy[vs2].empty() && lazy_q[vs1] == q && lazy_q[vs2] == q &&
                           dead_from(vp, pc + 1, vd == vs1 ? vs2 : vs1);
-    if (!is_cfg && !fold_add) {
+    // ... and `vfqadd.vs / vfqsub.vs acc, acc, c` on a lazy sum appends a CONSTANT term (rounding offsets of the
+    // mod-down, keyswitch.mem:81,:87): the sum stays lazy.
+    const bool fold_const = fuse && (funct6 == 0x05 || funct6 == 0x09) && funct3 == 1 && !lazy[vs1].empty() &&
+                            lazy_q[vs1] == q && (vd == vs1 || dead_from(vp, pc + 1, vs1)) &&
+                            lazy[vs1].size() < (size_t)aloha::k::kDotTerms;
+    if (!is_cfg && !fold_add && !fold_const) {
       const bool lazy_store = funct6 == 0x07 && !lazy[vs1].empty() && dead_from(vp, pc + 1, vs1);
       for (unsigned r = 0; r < ALOHA_NVREG; r++)
         if (!lazy[r].empty() && reads_reg(d, r) && !lazy_store) ALOHA_RUN_CK(materialise(r, nullptr, n));
@@ -744,6 +749,15 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         } else ALOHA_RUN_FAIL(ALOHA_ERR_DECODE, "pc %u: funct3 %u on funct6 %#x", pc, funct3, funct6);
         s = s >= q ? s - q : s;                                    // the scalar is normalised like a lane input (modalu.sv:46)
         if (s >= q) ALOHA_RUN_FAIL(ALOHA_ERR_ARG, "pc %u: scalar operand %#llx >= 2q", pc, (u64)imm);
+        if (fold_const) {                                          // sum +- c: one more term, no operand
+          std::vector<LazyTerm> terms;
+          terms.swap(lazy[vs1]);
+          terms.push_back(LazyTerm{nullptr, nullptr, funct6 == 0x05 ? s : (s ? q - s : 0)});
+          lazy[vd].swap(terms);
+          lazy_q[vd] = q;
+          alias[vd] = nullptr;
+          break;
+        }
         if (fold_add) {                                            // acc += t  with both sides lazy: concatenate the sums
           const unsigned t = vd == vs1 ? vs2 : vs1;
           lazy[vd].insert(lazy[vd].end(), lazy[t].begin(), lazy[t].end());
@@ -885,7 +899,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         if (!p) ALOHA_RUN_FAIL(ALOHA_ERR_ADDR, "pc %u: vse imm %#llx out of range", pc, (u64)imm);
         if (!lazy[vs1].empty()) {                                  // (only reached when vs1 is dead afterwards)
           bool clash = false;                                      // the sum must not read what it overwrites
-          for (const auto &t : lazy[vs1]) clash |= overlap(t.first, p, n) || (t.second && overlap(t.second, p, n));
+          for (const auto &t : lazy[vs1]) clash |= (t.first && overlap(t.first, p, n)) || (t.second && overlap(t.second, p, n));
           if (!clash) {
             std::vector<LazyTerm> terms;
             terms.swap(lazy[vs1]);                                 // keep before_mem_write from evaluating it twice
@@ -905,9 +919,9 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
                 for (const auto &g : dot_batch) {
                   if (overlap(p, g.d, n)) return false;
                   for (int t = 0; t < g.nterms; t++)
-                    if (overlap(p, g.a[t], n) || (g.b[t] && overlap(p, g.b[t], n))) return false;
+                    if ((g.a[t] && overlap(p, g.a[t], n)) || (g.b[t] && overlap(p, g.b[t], n))) return false;
                   for (const auto &t : lazy[vs1])
-                    if (overlap(t.first, g.d, n) || (t.second && overlap(t.second, g.d, n))) return false;
+                    if ((t.first && overlap(t.first, g.d, n)) || (t.second && overlap(t.second, g.d, n))) return false;
                 }
                 return true;
               };
@@ -916,7 +930,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
               g.nterms = (int)lazy[vs1].size();
               for (int t = 0; t < g.nterms; t++) {
                 g.a[t] = lazy[vs1][t].first; g.b[t] = lazy[vs1][t].second; g.s[t] = lazy[vs1][t].s;
-                g.sp[t] = g.b[t] ? 0 : aloha::nt::shoup(g.s[t], lazy_q[vs1]);
+                g.sp[t] = (g.b[t] || !g.a[t]) ? 0 : aloha::nt::shoup(g.s[t], lazy_q[vs1]);
               }
               g.init = nullptr; g.d = p; g.m = modctx(lazy_q[vs1]);
               dot_batch.push_back(g);
@@ -925,7 +939,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
                 if (!hi || x + n > hi) hi = x + n;
               };
               grow(p, dot_w_lo, dot_w_hi);
-              for (int t = 0; t < g.nterms; t++) { grow(g.a[t], dot_a_lo, dot_a_hi); if (g.b[t]) grow(g.b[t], dot_b_lo, dot_b_hi); }
+              for (int t = 0; t < g.nterms; t++) {
+                if (g.a[t]) grow(g.a[t], dot_a_lo, dot_a_hi);
+                if (g.b[t]) grow(g.b[t], dot_b_lo, dot_b_hi);
+              }
               pend_kind = PK_DOT; batch_logn = logn;
               lazy[vs1].clear();
               break;

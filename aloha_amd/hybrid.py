@@ -18,7 +18,7 @@ parity is against the oracle's ISA machine plus decryption semantics (tests/ckks
                      SD[j][d] = NTT_j( sum_{i in D_d} Y[i] * (Q_d/q_i mod m_j)  mod m_j )
                  (for m_j in D_d the digit's limb under m_j is X[j] itself)
     phase 2b     acc_c[j] = sum_d SD[j][d] * KEY[j][d][c]
-    phase 3      owners of p_k:  W[k][c] = (iNTT(acc_c[p_k]) + floor(P/2)) * (P/p_k)^-1  mod p_k
+    phase 3      owners of p_k:  W[k][c] = (iNTT(acc_c[p_k]) + floor(P/2)) * (P/p_k)^-1  mod p_k   (a one-term sum + constant)
     exchange     ALL-GATHER of W (2K limbs)
     phase 4      t_c[j] = NTT_j( sum_k W[k][c] * (P/p_k mod q_j) - floor(P/2) );
                  r_c[j] = (acc_c[j] - t_c[j]) * P^-1 mod q_j;   out = (ROT + r_0, [BASE1 +] r_1)
@@ -126,14 +126,20 @@ def _pack(blocks: Sequence[Sequence[str]], n: int) -> List[List[str]]:
     return progs
 
 
-def _scalar_sum(srcs: Sequence[int], scalars: Sequence[int], dst_off: int) -> List[str]:
-    """dst = sum_t mem[srcs[t]] * scalars[t] under the current modulus, as a foldable chain."""
+def _scalar_sum(srcs: Sequence[int], scalars: Sequence[int], dst_off: int, minus: Optional[int] = None,
+                plus: Optional[int] = None) -> List[str]:
+    """dst = sum_t mem[srcs[t]] * scalars[t] [- minus] [+ plus] under the current modulus, as a foldable chain
+    (the engine evaluates it in one pass over its operands)."""
     out = []
     for t, (s, c) in enumerate(zip(srcs, scalars)):
         if t == 0:
             out += [f"vle v0, abs+{s:#x}", f"vfqmul.vs v6, v0, {c:#x}"]
         else:
             out += [f"vle v0, abs+{s:#x}", f"vfqmul.vs v3, v0, {c:#x}", "vfqadd.vv v6, v6, v3"]
+    if minus is not None:
+        out.append(f"vfqsub.vs v6, v6, {minus:#x}")
+    if plus is not None:
+        out.append(f"vfqadd.vs v6, v6, {plus:#x}")
     return out + [f"vse v6, abs+{dst_off:#x}"]
 
 
@@ -204,8 +210,9 @@ def blocks_inner(lo: HybridLayout) -> List[List[str]]:
 
 
 def blocks_moddown_terms(lo: HybridLayout) -> List[List[str]]:
-    """Three loops (transforms, rounding constant, scaling) so that each is one batched launch; the
-    special primes' accumulators are transformed in place (they are not needed again)."""
+    """Two loops, each one batched launch: the special primes' accumulators to coefficient form (in place,
+    they are not needed again), then W = (x + floor(P/2)) * (P/p_k)^-1 = x*c + floor(P/2)*c as a one-term sum
+    with a constant."""
     b = []
     acc = lambda k, c: lo.off(lo.acc + 2 * lo.owned_all.index(lo.L + k) + c)
     for k in lo.owned_sp:
@@ -215,36 +222,25 @@ def blocks_moddown_terms(lo: HybridLayout) -> List[List[str]]:
         b.append(blk)
     for k in lo.owned_sp:
         p = lo.specials[k]
-        blk = _setq(p)
-        for c in range(2):
-            blk += [f"vle v0, abs+{acc(k, c):#x}", f"vfqadd.vs v2, v0, {lo.half % p:#x}", f"vse v2, abs+{acc(k, c):#x}"]
-        b.append(blk)
-    for k in lo.owned_sp:
-        p = lo.specials[k]
         cinv = _inv(lo.P // p, p)
         blk = _setq(p)
         for c in range(2):
-            blk += [f"vle v0, abs+{acc(k, c):#x}", f"vfqmul.vs v2, v0, {cinv:#x}", f"vse v2, abs+{lo.off(lo.w_slot(k, c)):#x}"]
+            blk += _scalar_sum([acc(k, c)], [cinv], lo.off(lo.w_slot(k, c)), plus=(lo.half % p) * cinv % p)
         b.append(blk)
     return b
 
 
 def blocks_finish(lo: HybridLayout, add_base1: bool) -> List[List[str]]:
+    """t = sum_k W_k * (P/p_k mod q_j) - floor(P/2)  (one fused sum), NTT, then
+    out_c = acc_c * P^-1 + t_c * (-P^-1) + base_c  (one fused sum): two launches besides the transform."""
     b = []
     own = list(enumerate(lo.owned_ct))
-    for i, j in own:                                            # P-basis -> q_j
+    for i, j in own:                                            # P-basis -> q_j, minus the rounding offset
         q = lo.moduli[j]
         blk = _setq(q)
         for c in range(2):
             blk += _scalar_sum([lo.off(lo.w_slot(k, c)) for k in range(lo.K)], [(lo.P // lo.specials[k]) % q for k in range(lo.K)],
-                               lo.off(lo.s1 + c * lo.Lr + i))
-        b.append(blk)
-    for i, j in own:                                            # - floor(P/2)
-        q = lo.moduli[j]
-        blk = _setq(q)
-        for c in range(2):
-            s = lo.off(lo.s1 + c * lo.Lr + i)
-            blk += [f"vle v0, abs+{s:#x}", f"vfqsub.vs v2, v0, {lo.half % q:#x}", f"vse v2, abs+{lo.off(lo.s2 + c * lo.Lr + i):#x}"]
+                               lo.off(lo.s2 + c * lo.Lr + i), minus=lo.half % q)
         b.append(blk)
     for i, j in own:                                            # to NTT form (in place)
         blk = _setq(lo.moduli[j])
@@ -252,26 +248,19 @@ def blocks_finish(lo: HybridLayout, add_base1: bool) -> List[List[str]]:
             s = lo.off(lo.s2 + c * lo.Lr + i)
             blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
         b.append(blk)
-    for i, j in own:                                            # acc - that
-        jl = lo.owned_all.index(j)
-        blk = _setq(lo.moduli[j])
-        for c in range(2):
-            blk += [f"vle v0, abs+{lo.off(lo.acc + 2 * jl + c):#x}", f"vle v1, abs+{lo.off(lo.s2 + c * lo.Lr + i):#x}",
-                    "vfqsub.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.s1 + c * lo.Lr + i):#x}"]
-        b.append(blk)
-    for i, j in own:                                            # times P^-1
+    for i, j in own:                                            # (acc - t) * P^-1 + base, as a sum of scaled operands
         q = lo.moduli[j]
+        jl = lo.owned_all.index(j)
         pinv = _inv(lo.P, q)
-        b.append(_setq(q) + [
-            f"vle v0, abs+{lo.off(lo.s1 + i):#x}", f"vfqmul.vs v2, v0, {pinv:#x}", f"vse v2, abs+{lo.off(lo.s2 + i):#x}",
-            f"vle v0, abs+{lo.off(lo.s1 + lo.Lr + i):#x}", f"vfqmul.vs v2, v0, {pinv:#x}",
-            f"vse v2, abs+{lo.off((lo.s2 if add_base1 else lo.out) + lo.Lr + i):#x}"])
-    for i, j in own:                                            # + ROT (and BASE1)
-        blk = _setq(lo.moduli[j]) + [f"vle v0, abs+{lo.off(lo.s2 + i):#x}", f"vle v1, abs+{lo.off(lo.rot + i):#x}",
-                                     "vfqadd.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.out + i):#x}"]
-        if add_base1:
-            blk += [f"vle v0, abs+{lo.off(lo.s2 + lo.Lr + i):#x}", f"vle v1, abs+{lo.off(lo.base1 + i):#x}",
-                    "vfqadd.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.out + lo.Lr + i):#x}"]
+        blk = _setq(q)
+        for c in range(2):
+            srcs = [lo.off(lo.acc + 2 * jl + c), lo.off(lo.s2 + c * lo.Lr + i)]
+            scal = [pinv, q - pinv]
+            if c == 0:
+                srcs.append(lo.off(lo.rot + i)); scal.append(1)
+            elif add_base1:
+                srcs.append(lo.off(lo.base1 + i)); scal.append(1)
+            blk += _scalar_sum(srcs, scal, lo.off(lo.out + c * lo.Lr + i))
         b.append(blk)
     return b
 

@@ -442,8 +442,12 @@ def _random_program(rng, n, primes, nslots, length):
                     lines += [f"vle v0, {slot()}"]
                     lines += [f"vfqmul.vs v{acc}, v0, {sc:#x}"] if i == 0 else [f"vfqmul.vs v{t}, v0, {sc:#x}", f"vfqadd.vv v{acc}, v{acc}, v{t}"]
             defined.update({0, acc}); defined.add(t) if i else None
-            choice = int(rng.integers(3))
-            if choice == 0:
+            choice = int(rng.integers(4))
+            if choice == 3:                                  # constant terms folded into the sum, then stored
+                for _ in range(int(rng.integers(1, 3))):
+                    lines.append(f"{rng.choice(['vfqadd.vs', 'vfqsub.vs'])} v{acc}, v{acc}, {int(rng.integers(0, 1 << 60)):#x}")
+                lines.append(f"vse v{acc}, {slot()}")
+            elif choice == 0:
                 lines.append(f"vse v{acc}, {slot()}")
             elif choice == 1:                                # a lazy value read by another op: must be evaluated first
                 lines.append(f"vfqsub.vs v2, v{acc}, {int(rng.integers(1, 1 << 59)):#x}"); defined.add(2)
