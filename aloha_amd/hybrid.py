@@ -31,6 +31,11 @@ a small multiple of Q_d, which the key's structure cancels mod Q.
 
 Key layout: limb ((jl*dnum + d)*2 + c) for owned modulus jl, digit d, component c -- the
 reference's [modulus][digit][component] order (keyswitch.mem:46-77) with dnum digits.
+
+``batch = B`` switches B ciphertexts per call with the same key (B products relinearised with the
+one relinearisation key, or B ciphertexts rotated by the same step): every loop of every phase
+then covers B times as many limbs, which is what fills the chip when the limbs are spread over 8
+ranks (3-4 moduli each) -- the launch count per call does not change.
 """
 from __future__ import annotations
 
@@ -50,10 +55,12 @@ def _prod(xs):
 
 
 class HybridLayout:
+    """Slots of N/128 rows from ``base_row``; every group holds ``B`` ciphertexts, index*B + b."""
+
     def __init__(self, n: int, moduli: Sequence[int], specials: Sequence[int], alpha: int, world: int = 1,
-                 rank: int = 0, base_row: int = 0):
+                 rank: int = 0, base_row: int = 0, batch: int = 1):
         self.n, self.moduli, self.specials, self.alpha = n, [int(q) for q in moduli], [int(p) for p in specials], alpha
-        self.world, self.rank, self.base_row = world, rank, base_row
+        self.world, self.rank, self.base_row, self.B = world, rank, base_row, batch
         self.L, self.K = len(self.moduli), len(self.specials)
         self.mods_all = self.moduli + self.specials
         self.dnum = -(-self.L // alpha)
@@ -64,21 +71,20 @@ class HybridLayout:
         self.Lr, self.Mr = len(self.owned_ct), len(self.owned_all)
         self.Yr = -(-self.L // world)
         self.Wr = 2 * max(1, max(sum(1 for k in range(self.K) if owner(self.L + k, world) == r) for r in range(world)))
-        s = 0
-        self.ct_in = s; s += 2 * self.Lr
-        self.ct_b = s; s += 2 * self.Lr
-        self.x = s; s += self.Lr
-        self.rot = s; s += self.Lr
-        self.base1 = s; s += self.Lr
-        self.y = s; s += world * self.Yr
-        self.sd = s; s += self.Mr * self.dnum
-        self.acc = s; s += 2 * self.Mr
-        self.w = s; s += world * self.Wr
-        self.out = s; s += 2 * self.Lr
-        self.s1 = s; s += 2 * self.Lr
-        self.s2 = s; s += 2 * self.Lr
+        B, s = batch, 0
+        self.ct_in = s; s += 2 * self.Lr * B
+        self.ct_b = s; s += 2 * self.Lr * B
+        self.x = s; s += self.Lr * B
+        self.rot = s; s += self.Lr * B
+        self.base1 = s; s += self.Lr * B
+        self.y = s; s += world * self.Yr * B
+        self.sd = s; s += self.Mr * self.dnum * B
+        self.acc = s; s += 2 * self.Mr * B
+        self.w = s; s += world * self.Wr * B
+        self.out = s; s += 2 * self.Lr * B
+        self.s1 = s; s += 2 * self.Lr * B
+        self.s2 = s; s += 2 * self.Lr * B
         self.slots = s
-        # constants
         self.P = _prod(self.specials)
         self.half = self.P // 2
 
@@ -91,13 +97,25 @@ class HybridLayout:
     def off(self, slot: int) -> int:
         return self.row(slot) * 1024
 
-    def y_slot(self, i: int) -> int:
-        return self.y + owner(i, self.world) * self.Yr + i // self.world
+    # slot of (group, index, ciphertext b)
+    def s_in(self, c, i, b=0): return self.ct_in + (c * self.Lr + i) * self.B + b
+    def s_inb(self, c, i, b=0): return self.ct_b + (c * self.Lr + i) * self.B + b
+    def s_x(self, i, b=0): return self.x + i * self.B + b
+    def s_rot(self, i, b=0): return self.rot + i * self.B + b
+    def s_base1(self, i, b=0): return self.base1 + i * self.B + b
+    def s_out(self, c, i, b=0): return self.out + (c * self.Lr + i) * self.B + b
+    def s_s1(self, c, i, b=0): return self.s1 + (c * self.Lr + i) * self.B + b
+    def s_s2(self, c, i, b=0): return self.s2 + (c * self.Lr + i) * self.B + b
+    def s_sd(self, jl, d, b=0): return self.sd + (jl * self.dnum + d) * self.B + b
+    def s_acc(self, jl, c, b=0): return self.acc + (2 * jl + c) * self.B + b
 
-    def w_slot(self, k: int, c: int) -> int:
+    def y_slot(self, i: int, b: int = 0) -> int:                 # gather buffer: rank r owns [r*Yr*B, (r+1)*Yr*B)
+        return self.y + (owner(i, self.world) * self.Yr + i // self.world) * self.B + b
+
+    def w_slot(self, k: int, c: int, b: int = 0) -> int:
         r = owner(self.L + k, self.world)
         kl = sum(1 for k2 in range(k) if owner(self.L + k2, self.world) == r)
-        return self.w + r * self.Wr + 2 * kl + c
+        return self.w + (r * self.Wr + 2 * kl + c) * self.B + b
 
     @property
     def spm_rows_needed(self) -> int:
@@ -144,36 +162,46 @@ def _scalar_sum(srcs: Sequence[int], scalars: Sequence[int], dst_off: int, minus
 
 
 def blocks_phase1(lo: HybridLayout, mode: str) -> List[List[str]]:
-    b = []
-    a = lambda c, i: lo.off(lo.ct_in + c * lo.Lr + i)
-    bb = lambda c, i: lo.off(lo.ct_b + c * lo.Lr + i)
+    b, o, B = [], lo.off, range(lo.B)
     own = list(enumerate(lo.owned_ct))
     if mode == "rotate":
         for i, j in own:                                        # NTT-domain automorphism of both components
-            b.append(_setq(lo.moduli[j]) + [f"vle v0, abs+{a(0, i):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{lo.off(lo.rot + i):#x}",
-                                            f"vle v0, abs+{a(1, i):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{lo.off(lo.x + i):#x}"])
+            for bi in B:
+                b.append(_setq(lo.moduli[j]) + [
+                    f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{o(lo.s_rot(i, bi)):#x}",
+                    f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{o(lo.s_x(i, bi)):#x}"])
     else:                                                       # tensor product
         for i, j in own:
-            b.append(_setq(lo.moduli[j]) + [
-                f"vle v0, abs+{a(0, i):#x}", f"vle v1, abs+{bb(0, i):#x}", "vfqmul.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.rot + i):#x}",
-                f"vle v0, abs+{a(1, i):#x}", f"vle v1, abs+{bb(1, i):#x}", "vfqmul.vv v2, v0, v1", f"vse v2, abs+{lo.off(lo.x + i):#x}"])
+            for bi in B:
+                b.append(_setq(lo.moduli[j]) + [
+                    f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(0, i, bi)):#x}", "vfqmul.vv v2, v0, v1",
+                    f"vse v2, abs+{o(lo.s_rot(i, bi)):#x}",
+                    f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(1, i, bi)):#x}", "vfqmul.vv v2, v0, v1",
+                    f"vse v2, abs+{o(lo.s_x(i, bi)):#x}"])
         for i, j in own:
-            b.append(_setq(lo.moduli[j]) + [
-                f"vle v0, abs+{a(0, i):#x}", f"vle v1, abs+{bb(1, i):#x}", "vfqmul.vv v6, v0, v1",
-                f"vle v0, abs+{a(1, i):#x}", f"vle v1, abs+{bb(0, i):#x}", "vfqmul.vv v3, v0, v1", "vfqadd.vv v6, v6, v3",
-                f"vse v6, abs+{lo.off(lo.base1 + i):#x}"])
+            for bi in B:
+                b.append(_setq(lo.moduli[j]) + [
+                    f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(1, i, bi)):#x}", "vfqmul.vv v6, v0, v1",
+                    f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(0, i, bi)):#x}", "vfqmul.vv v3, v0, v1",
+                    "vfqadd.vv v6, v6, v3", f"vse v6, abs+{o(lo.s_base1(i, bi)):#x}"])
     for i, j in own:                                            # coefficient form
-        b.append(_setq(lo.moduli[j]) + [f"vle v0, abs+{lo.off(lo.x + i):#x}", "vintt v2, v0", f"vse v2, abs+{lo.off(lo.s1 + i):#x}"])
+        blk = _setq(lo.moduli[j])
+        for bi in B:
+            blk += [f"vle v0, abs+{o(lo.s_x(i, bi)):#x}", "vintt v2, v0", f"vse v2, abs+{o(lo.s_s1(0, i, bi)):#x}"]
+        b.append(blk)
     for i, j in own:                                            # times (Q_d/q_j)^-1 mod q_j
         q = lo.moduli[j]
         dig = lo.digit(j // lo.alpha)
         c = _inv(_prod(lo.moduli[t] for t in dig if t != j), q)
-        b.append(_setq(q) + [f"vle v0, abs+{lo.off(lo.s1 + i):#x}", f"vfqmul.vs v2, v0, {c:#x}", f"vse v2, abs+{lo.off(lo.y_slot(j)):#x}"])
+        blk = _setq(q)
+        for bi in B:
+            blk += [f"vle v0, abs+{o(lo.s_s1(0, i, bi)):#x}", f"vfqmul.vs v2, v0, {c:#x}", f"vse v2, abs+{o(lo.y_slot(j, bi)):#x}"]
+        b.append(blk)
     return b
 
 
 def blocks_modup(lo: HybridLayout) -> List[List[str]]:
-    b = []
+    b, o, B = [], lo.off, range(lo.B)
     for jl, j in enumerate(lo.owned_all):                       # basis extension sums
         m = lo.mods_all[j]
         for d in range(lo.dnum):
@@ -181,31 +209,34 @@ def blocks_modup(lo: HybridLayout) -> List[List[str]]:
             if j in dig:
                 continue
             scal = [_prod(lo.moduli[t] for t in dig if t != i) % m for i in dig]
-            b.append(_setq(m) + _scalar_sum([lo.off(lo.y_slot(i)) for i in dig], scal, lo.off(lo.sd + jl * lo.dnum + d)))
+            for bi in B:
+                b.append(_setq(m) + _scalar_sum([o(lo.y_slot(i, bi)) for i in dig], scal, o(lo.s_sd(jl, d, bi))))
     for jl, j in enumerate(lo.owned_all):                       # to NTT form, in place
         m = lo.mods_all[j]
         blk = _setq(m)
         for d in range(lo.dnum):
             if j in lo.digit(d):
                 continue
-            s = lo.off(lo.sd + jl * lo.dnum + d)
-            blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
+            for bi in B:
+                s = o(lo.s_sd(jl, d, bi))
+                blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
         b.append(blk)
     return b
 
 
 def blocks_inner(lo: HybridLayout) -> List[List[str]]:
-    b = []
+    b, o = [], lo.off
     for jl, j in enumerate(lo.owned_all):
-        blk = _setq(lo.mods_all[j])
-        for c in range(2):
-            acc = 6 + 2 * c
-            for d in range(lo.dnum):
-                src = lo.off(lo.x + lo.owned_ct.index(j)) if j in lo.digit(d) else lo.off(lo.sd + jl * lo.dnum + d)
-                blk += [f"vle v0, abs+{src:#x}", f"vle v1, ksk+{((jl * lo.dnum + d) * 2 + c) * 8 * lo.n:#x}"]
-                blk += [f"vfqmul.vv v{acc}, v0, v1"] if d == 0 else ["vfqmul.vv v3, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v3"]
-            blk.append(f"vse v{acc}, abs+{lo.off(lo.acc + 2 * jl + c):#x}")
-        b.append(blk)
+        for bi in range(lo.B):
+            blk = _setq(lo.mods_all[j])
+            for c in range(2):
+                acc = 6 + 2 * c
+                for d in range(lo.dnum):
+                    src = o(lo.s_x(lo.owned_ct.index(j), bi)) if j in lo.digit(d) else o(lo.s_sd(jl, d, bi))
+                    blk += [f"vle v0, abs+{src:#x}", f"vle v1, ksk+{((jl * lo.dnum + d) * 2 + c) * 8 * lo.n:#x}"]
+                    blk += [f"vfqmul.vv v{acc}, v0, v1"] if d == 0 else ["vfqmul.vv v3, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v3"]
+                blk.append(f"vse v{acc}, abs+{o(lo.s_acc(jl, c, bi)):#x}")
+            b.append(blk)
     return b
 
 
@@ -213,65 +244,64 @@ def blocks_moddown_terms(lo: HybridLayout) -> List[List[str]]:
     """Two loops, each one batched launch: the special primes' accumulators to coefficient form (in place,
     they are not needed again), then W = (x + floor(P/2)) * (P/p_k)^-1 = x*c + floor(P/2)*c as a one-term sum
     with a constant."""
-    b = []
-    acc = lambda k, c: lo.off(lo.acc + 2 * lo.owned_all.index(lo.L + k) + c)
+    b, o, B = [], lo.off, range(lo.B)
+    acc = lambda k, c, bi: o(lo.s_acc(lo.owned_all.index(lo.L + k), c, bi))
     for k in lo.owned_sp:
         blk = _setq(lo.specials[k])
         for c in range(2):
-            blk += [f"vle v0, abs+{acc(k, c):#x}", "vintt v2, v0", f"vse v2, abs+{acc(k, c):#x}"]
+            for bi in B:
+                blk += [f"vle v0, abs+{acc(k, c, bi):#x}", "vintt v2, v0", f"vse v2, abs+{acc(k, c, bi):#x}"]
         b.append(blk)
     for k in lo.owned_sp:
         p = lo.specials[k]
         cinv = _inv(lo.P // p, p)
-        blk = _setq(p)
         for c in range(2):
-            blk += _scalar_sum([acc(k, c)], [cinv], lo.off(lo.w_slot(k, c)), plus=(lo.half % p) * cinv % p)
-        b.append(blk)
+            for bi in B:
+                b.append(_setq(p) + _scalar_sum([acc(k, c, bi)], [cinv], o(lo.w_slot(k, c, bi)), plus=(lo.half % p) * cinv % p))
     return b
 
 
 def blocks_finish(lo: HybridLayout, add_base1: bool) -> List[List[str]]:
     """t = sum_k W_k * (P/p_k mod q_j) - floor(P/2)  (one fused sum), NTT, then
     out_c = acc_c * P^-1 + t_c * (-P^-1) + base_c  (one fused sum): two launches besides the transform."""
-    b = []
+    b, o, B = [], lo.off, range(lo.B)
     own = list(enumerate(lo.owned_ct))
     for i, j in own:                                            # P-basis -> q_j, minus the rounding offset
         q = lo.moduli[j]
-        blk = _setq(q)
         for c in range(2):
-            blk += _scalar_sum([lo.off(lo.w_slot(k, c)) for k in range(lo.K)], [(lo.P // lo.specials[k]) % q for k in range(lo.K)],
-                               lo.off(lo.s2 + c * lo.Lr + i), minus=lo.half % q)
-        b.append(blk)
+            for bi in B:
+                b.append(_setq(q) + _scalar_sum([o(lo.w_slot(k, c, bi)) for k in range(lo.K)],
+                                                [(lo.P // lo.specials[k]) % q for k in range(lo.K)], o(lo.s_s2(c, i, bi)), minus=lo.half % q))
     for i, j in own:                                            # to NTT form (in place)
         blk = _setq(lo.moduli[j])
         for c in range(2):
-            s = lo.off(lo.s2 + c * lo.Lr + i)
-            blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
+            for bi in B:
+                s = o(lo.s_s2(c, i, bi))
+                blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
         b.append(blk)
     for i, j in own:                                            # (acc - t) * P^-1 + base, as a sum of scaled operands
         q = lo.moduli[j]
         jl = lo.owned_all.index(j)
         pinv = _inv(lo.P, q)
-        blk = _setq(q)
         for c in range(2):
-            srcs = [lo.off(lo.acc + 2 * jl + c), lo.off(lo.s2 + c * lo.Lr + i)]
-            scal = [pinv, q - pinv]
-            if c == 0:
-                srcs.append(lo.off(lo.rot + i)); scal.append(1)
-            elif add_base1:
-                srcs.append(lo.off(lo.base1 + i)); scal.append(1)
-            blk += _scalar_sum(srcs, scal, lo.off(lo.out + c * lo.Lr + i))
-        b.append(blk)
+            for bi in B:
+                srcs = [o(lo.s_acc(jl, c, bi)), o(lo.s_s2(c, i, bi))]
+                scal = [pinv, q - pinv]
+                if c == 0:
+                    srcs.append(o(lo.s_rot(i, bi))); scal.append(1)
+                elif add_base1:
+                    srcs.append(o(lo.s_base1(i, bi))); scal.append(1)
+                b.append(_setq(q) + _scalar_sum(srcs, scal, o(lo.s_out(c, i, bi))))
     return b
 
 
 class HybridKeySwitch:
-    """Rotate / multiply with the hybrid key-switch on one rank of ``world``."""
+    """Rotate / multiply with the hybrid key-switch on one rank of ``world``; ``batch`` ciphertexts per call."""
 
     def __init__(self, vp, n: int, moduli: Sequence[int], specials: Sequence[int], alpha: int, world: int = 1, rank: int = 0,
-                 exchange: Optional[Exchange] = None, base_row: int = 0):
+                 exchange: Optional[Exchange] = None, base_row: int = 0, batch: int = 1):
         self.vp = vp
-        self.lo = lo = HybridLayout(n, moduli, specials, alpha, world, rank, base_row)
+        self.lo = lo = HybridLayout(n, moduli, specials, alpha, world, rank, base_row, batch)
         self.ex = exchange or Exchange()
         asm = lambda progs: [isa.assemble("\n".join(p)) for p in progs]
         self._p = {
@@ -301,23 +331,28 @@ class HybridKeySwitch:
         for jl, j in enumerate(lo.owned_all):
             self.vp.write(KSK, jl * lo.dnum * 2 * lo.rows, k[j])
 
-    def _load(self, slot0: int, ct_full: np.ndarray) -> None:
+    def _load(self, slot_of, ct_full: np.ndarray, b: int) -> None:
         lo = self.lo
         ct = np.ascontiguousarray(ct_full, dtype=np.uint64).reshape(2, lo.L, lo.n)
         for c in range(2):
             for i, j in enumerate(lo.owned_ct):
-                self.vp.write(SPM, lo.row(slot0 + c * lo.Lr + i), ct[c, j])
+                self.vp.write(SPM, lo.row(slot_of(c, i, b)), ct[c, j])
 
-    def load_ct(self, ct_full: np.ndarray) -> None:
-        self._load(self.lo.ct_in, ct_full)
+    def load_ct(self, ct_full: np.ndarray, b: int = 0) -> None:
+        self._load(self.lo.s_in, ct_full, b)
 
-    def load_ct_b(self, ct_full: np.ndarray) -> None:
-        self._load(self.lo.ct_b, ct_full)
+    def load_ct_b(self, ct_full: np.ndarray, b: int = 0) -> None:
+        self._load(self.lo.s_inb, ct_full, b)
 
-    def read_out(self) -> np.ndarray:
+    def read_out(self, b: int = 0) -> np.ndarray:
+        """Owned result limbs of ciphertext ``b``, shape (2, Lr, n)."""
         lo = self.lo
         self.vp.sync()
-        return self.vp.read(SPM, lo.row(lo.out), 2 * lo.Lr * lo.n).reshape(2, lo.Lr, lo.n)
+        out = np.empty((2, lo.Lr, lo.n), dtype=np.uint64)
+        for c in range(2):
+            for i in range(lo.Lr):
+                out[c, i] = self.vp.read(SPM, lo.row(lo.s_out(c, i, b)), lo.n)
+        return out
 
     # -- the ops ----------------------------------------------------------------------------------
     def _run(self, name: str, step: int = 0) -> None:
@@ -334,10 +369,10 @@ class HybridKeySwitch:
 
     def _switch(self, finish: str) -> None:
         lo = self.lo
-        self.ex.all_gather(self.vp, lo.row(lo.y), lo.Yr * lo.n, lo.world, lo.rank)
+        self.ex.all_gather(self.vp, lo.row(lo.y), lo.Yr * lo.B * lo.n, lo.world, lo.rank)
         self._run("mid")
         self._run("terms")
-        self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.n, lo.world, lo.rank)
+        self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.B * lo.n, lo.world, lo.rank)
         self._run(finish)
 
     def rotate(self, k: int) -> None:

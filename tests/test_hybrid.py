@@ -128,11 +128,40 @@ def test_programs_fit_the_rom_and_layouts_partition(L, alpha, world):
     assert intt == L + 2 * K and ntt == dnum * (L + K) - L + 2 * L
 
 
+def _run_batch(vp, n, mods, specials, alpha, cts, key, op, k=0, **kw):
+    hs = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha, batch=len(cts), **kw)
+    hs.load_key(key)
+    for b, ct in enumerate(cts):
+        hs.load_ct(ct, b)
+        if op == "multiply":
+            hs.load_ct_b(cts[(b + 1) % len(cts)], b)
+    hs.multiply() if op == "multiply" else hs.rotate(k)
+    return hs
+
+
+@pytest.mark.parametrize("op", ["rotate", "multiply"])
+def test_batched_switch_equals_one_ciphertext_at_a_time(op):
+    """batch = 3 ciphertexts under one key in one call == three separate calls (oracle machine, ragged digits)."""
+    n, L, K, alpha, k = 1024, 5, 2, 2, pow(3, 9, 2048)
+    mods, specials, ct, key = _random_case(n, L, K, alpha, 23)
+    rng = np.random.default_rng(5)
+    cts = [ct] + [np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)]) for _ in range(2)]
+    hs = _run_batch(oracle.OracleVP(spm_rows=1 << 15, ksk_rows=1 << 14), n, mods, specials, alpha, cts, key, op, k)
+    for b in range(3):
+        one = hybrid.HybridKeySwitch(oracle.OracleVP(spm_rows=1 << 14, ksk_rows=1 << 14), n, mods, specials, alpha)
+        one.load_key(key); one.load_ct(cts[b])
+        if op == "multiply":
+            one.load_ct_b(cts[(b + 1) % 3]); one.multiply()
+        else:
+            one.rotate(k)
+        assert np.array_equal(hs.read_out(b), one.read_out()), (op, b)
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, L, K, alpha, seed, k, op, out_dir, engine):
+def _worker(rank, world, port, n, L, K, alpha, seed, k, op, out_dir, engine, batch=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -143,9 +172,15 @@ def _worker(rank, world, port, n, L, K, alpha, seed, k, op, out_dir, engine):
             vp = avp.VP(spm_rows=1 << 15, ksk_rows=1 << 15, max_log_n=16, device=0)
         else:
             vp = oracle.OracleVP(spm_rows=1 << 14, ksk_rows=1 << 14)
-        hs = _run(vp, n, mods, specials, alpha, ct, key, op, k, world=world, rank=rank,
-                  exchange=keyswitch.Exchange(group=None, tensor_of=None))
-        np.save(os.path.join(out_dir, f"out{rank}.npy"), hs.read_out())
+        if batch == 1:
+            hs = _run(vp, n, mods, specials, alpha, ct, key, op, k, world=world, rank=rank,
+                      exchange=keyswitch.Exchange(group=None, tensor_of=None))
+            np.save(os.path.join(out_dir, f"out{rank}.npy"), hs.read_out())
+        else:
+            cts = [np.roll(ct, b, axis=1) for b in range(batch)]
+            hs = _run_batch(vp, n, mods, specials, alpha, cts, key, op, k, world=world, rank=rank,
+                            exchange=keyswitch.Exchange(group=None, tensor_of=None))
+            np.save(os.path.join(out_dir, f"out{rank}.npy"), np.stack([hs.read_out(b) for b in range(batch)]))
         np.save(os.path.join(out_dir, f"own{rank}.npy"), np.array(hs.lo.owned_ct))
     finally:
         dist.destroy_process_group()
@@ -171,6 +206,22 @@ def _check_sharded(tmp_path, n, L, K, alpha, op, engine):
 def test_two_rank_hybrid_gloo(tmp_path, op):
     """L = 5, K = 2, alpha = 2 over two ranks (uneven shards, a special prime on each rank)."""
     _check_sharded(tmp_path, 1024, 5, 2, 2, op, "oracle")
+
+
+def test_two_rank_batched_hybrid_gloo(tmp_path):
+    """Two ranks, two ciphertexts per call: the gather buffers carry rank-major, ciphertext-minor chunks."""
+    n, L, K, alpha, seed, k, op = 1024, 5, 2, 2, 29, pow(3, 5, 2048), "multiply"
+    mods, specials, ct, key = _random_case(n, L, K, alpha, seed)
+    cts = [np.roll(ct, b, axis=1) for b in range(2)]
+    ref = _run_batch(oracle.OracleVP(spm_rows=1 << 15, ksk_rows=1 << 14), n, mods, specials, alpha, cts, key, op, k)
+    exp = np.stack([ref.read_out(b) for b in range(2)])
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n, L, K, alpha, seed, k, op, str(tmp_path), "oracle", 2), nprocs=2, join=True)
+    for r in range(2):
+        out = np.load(tmp_path / f"out{r}.npy")
+        own = np.load(tmp_path / f"own{r}.npy")
+        for i, j in enumerate(own):
+            assert np.array_equal(out[:, :, i], exp[:, :, j]), f"rank {r} limb {j}"
 
 
 @pytest.mark.gpu
@@ -201,3 +252,12 @@ def test_hybrid_on_gpu_matches_oracle_and_golden():
             with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
                 got = _run(vp, n, mods, specials, alpha, ct, key, op, k).read_out()
             assert np.array_equal(got, exp), (alpha, op)
+    # two ciphertexts per call on the GPU == the oracle machine
+    cts = [ct, np.roll(ct, 1, axis=1)]
+    lo = hybrid.HybridLayout(n, mods, specials, 4, batch=2)
+    ref = _run_batch(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows), n, mods, specials, 4, cts, key,
+                     "multiply")
+    with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
+        got = _run_batch(vp, n, mods, specials, 4, cts, key, "multiply")
+        for b in range(2):
+            assert np.array_equal(got.read_out(b), ref.read_out(b)), b

@@ -130,20 +130,22 @@ def config45(L):
             "hmult_algorithmic_GBps": alg / tm / 1e9}
 
 
-def hybrid45(L, alpha):
-    """Configs 4/5 with the hybrid key-switch (alpha primes per digit, K = alpha special primes, vautn)."""
+def hybrid45(L, alpha, batch=1):
+    """Configs 4/5 with the hybrid key-switch (alpha primes per digit, K = alpha special primes, vautn);
+    ``batch`` ciphertexts per call under one key (times are per call)."""
     from aloha_amd import hybrid
     logn, n, K = 16, 1 << 16, alpha
     mods = [avp.nth_prime(logn, i) for i in range(L)]
     specials = [avp.nth_prime(logn, L + k) for k in range(K)]
-    lo = hybrid.HybridLayout(n, mods, specials, alpha)
+    lo = hybrid.HybridLayout(n, mods, specials, alpha, batch=batch)
     rng = np.random.default_rng(6)
     with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
-        hs = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha)
+        hs = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha, batch=batch)
         for jl in range(lo.Mr):
             vp.write(KSK, jl * lo.dnum * 2 * lo.rows, rng.integers(0, lo.mods_all[jl], lo.dnum * 2 * n, dtype=np.uint64))
         ct = np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
-        hs.load_ct(ct); hs.load_ct_b(ct[::-1].copy())
+        for b in range(batch):
+            hs.load_ct(ct, b); hs.load_ct_b(ct[::-1].copy(), b)
         k = pow(3, 5, 2 * n)
         hs.rotate(k); vp.sync()
         l0 = vp.stats()["kernel_launches"]
@@ -152,7 +154,8 @@ def hybrid45(L, alpha):
         hs.multiply(); vp.sync()
         tm = timeit(lambda: hs.multiply(), vp.sync, 5)
         transforms = L + (lo.dnum * (L + K) - L) + 2 * K + 2 * L
-    return {"L": L, "alpha": alpha, "K": K, "dnum": lo.dnum, "rotate_keyswitch_ms": t * 1e3, "hmult_relin_ms": tm * 1e3,
+    return {"L": L, "alpha": alpha, "K": K, "dnum": lo.dnum, "batch": batch, "rotate_keyswitch_ms": t * 1e3, "hmult_relin_ms": tm * 1e3,
+            "hmult_relin_ms_per_ciphertext": tm * 1e3 / batch,
             "transforms_per_switch": transforms, "key_limbs": 2 * lo.dnum * (L + K), "kernel_launches_per_rotate": launches_rot}
 
 
@@ -181,7 +184,8 @@ if __name__ == "__main__":
             "config4_keyswitch_n65536_L24": lambda: config45(24), "config5_keyswitch_n65536_L32": lambda: config45(32),
             "config5_automorphism_batch": aut_batch,
             "hybrid_config4_L24_alpha4": lambda: hybrid45(24, 4), "hybrid_config5_L32_alpha4": lambda: hybrid45(32, 4),
-            "hybrid_config4_L24_alpha8": lambda: hybrid45(24, 8)}
+            "hybrid_config4_L24_alpha8": lambda: hybrid45(24, 8),
+            "hybrid_config4_L24_alpha4_batch4": lambda: hybrid45(24, 4, 4), "hybrid_config5_L32_alpha4_batch4": lambda: hybrid45(32, 4, 4)}
     only = [a for a in sys.argv[1:] if not a.startswith("-")]           # e.g. `config4` (prefix match), for profiling runs
     res = {k: f() for k, f in todo.items() if not only or any(k.startswith(o) for o in only)}
     print(json.dumps(res, indent=1))
