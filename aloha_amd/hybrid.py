@@ -36,6 +36,11 @@ reference's [modulus][digit][component] order (keyswitch.mem:46-77) with dnum di
 one relinearisation key, or B ciphertexts rotated by the same step): every loop of every phase
 then covers B times as many limbs, which is what fills the chip when the limbs are spread over 8
 ranks (3-4 moduli each) -- the launch count per call does not change.
+
+``rescale()`` is the leveled-CKKS step after a product, in the same style: the owner of q_{L-1}
+publishes v_c = iNTT(c_c[L-1]) + floor(q_{L-1}/2) (one all-gather of 2B limbs), every rank then
+forms out_c[j] = (c_c[j] - NTT_j(v_c - floor(q_{L-1}/2) mod q_j)) * q_{L-1}^-1 mod q_j for its
+j < L-1 -- the rounded division by the last prime, which decrypts to round(m / q_{L-1}) (tests).
 """
 from __future__ import annotations
 
@@ -116,6 +121,10 @@ class HybridLayout:
         r = owner(self.L + k, self.world)
         kl = sum(1 for k2 in range(k) if owner(self.L + k2, self.world) == r)
         return self.w + (r * self.Wr + 2 * kl + c) * self.B + b
+
+    def rescale_slot(self, c: int, b: int = 0) -> int:
+        """Coefficient-form last limb (+ rounding offset) in the W gather buffer: chunk of the owner of q_{L-1}."""
+        return self.w + (owner(self.L - 1, self.world) * self.Wr + c) * self.B + b
 
     @property
     def spm_rows_needed(self) -> int:
@@ -295,6 +304,53 @@ def blocks_finish(lo: HybridLayout, add_base1: bool) -> List[List[str]]:
     return b
 
 
+def blocks_rescale(lo: HybridLayout) -> List[List[List[str]]]:
+    """Rescale by the last ciphertext prime q_last (the leveled-CKKS step after a product): for j < L-1
+        out_c[j] = (c_c[j] - NTT_j(t_c)) * q_last^-1  mod q_j,   t_c = iNTT(c_c[L-1]) + floor(q_last/2)  (mod q_last)
+    with the rounding offset removed again under q_j -- the mod-down of the key-switch with P = q_last.
+    Two phases around one exchange (the coefficient-form last limb goes to every rank through the W buffer):
+    returns [blocks of the owner of q_last, blocks of every rank]."""
+    o, B, L = lo.off, range(lo.B), lo.L
+    qL = lo.moduli[L - 1]
+    half = qL // 2
+    first, second = [], []
+    if (L - 1) in lo.owned_ct:
+        iL = lo.owned_ct.index(L - 1)
+        blk = _setq(qL)
+        for c in range(2):
+            for bi in B:
+                blk += [f"vle v0, abs+{o(lo.s_in(c, iL, bi)):#x}", "vintt v2, v0", f"vse v2, abs+{o(lo.s_s1(c, iL, bi)):#x}"]
+        first.append(blk)
+        for c in range(2):
+            for bi in B:
+                first.append(_setq(qL) + _scalar_sum([o(lo.s_s1(c, iL, bi))], [1], o(lo.rescale_slot(c, bi)), plus=half))
+    for i, j in enumerate(lo.owned_ct):
+        if j == L - 1:
+            continue
+        q = lo.moduli[j]
+        for c in range(2):
+            for bi in B:                                        # t mod q_j, minus the rounding offset
+                second.append(_setq(q) + _scalar_sum([o(lo.rescale_slot(c, bi))], [1], o(lo.s_s2(c, i, bi)), minus=half % q))
+    for i, j in enumerate(lo.owned_ct):
+        if j == L - 1:
+            continue
+        blk = _setq(lo.moduli[j])
+        for c in range(2):
+            for bi in B:
+                s = o(lo.s_s2(c, i, bi))
+                blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
+        second.append(blk)
+    for i, j in enumerate(lo.owned_ct):
+        if j == L - 1:
+            continue
+        q = lo.moduli[j]
+        inv = _inv(qL, q)
+        for c in range(2):
+            for bi in B:
+                second.append(_setq(q) + _scalar_sum([o(lo.s_in(c, i, bi)), o(lo.s_s2(c, i, bi))], [inv, q - inv], o(lo.s_out(c, i, bi))))
+    return [first, second]
+
+
 class HybridKeySwitch:
     """Rotate / multiply with the hybrid key-switch on one rank of ``world``; ``batch`` ciphertexts per call."""
 
@@ -312,6 +368,9 @@ class HybridKeySwitch:
             "fin_rot": asm(_pack(blocks_finish(lo, False), n)) if lo.Lr else [],
             "fin_mul": asm(_pack(blocks_finish(lo, True), n)) if lo.Lr else [],
         }
+        rs = blocks_rescale(lo)
+        self._p["rescale1"] = asm(_pack(rs[0], n)) if rs[0] else []
+        self._p["rescale2"] = asm(_pack(rs[1], n)) if rs[1] else []
         total = sum(len(w) for ps in self._p.values() for w in ps)
         self._resident = total <= isa.IRAM_DEPTH
         self._pc = {}
@@ -382,3 +441,11 @@ class HybridKeySwitch:
     def multiply(self) -> None:
         self._run("mul1")
         self._switch("fin_mul")
+
+    def rescale(self) -> None:
+        """CT_IN (L limbs) -> OUT (limbs 0 .. L-2 valid): divide by the last ciphertext prime, rounding.
+        The product of two ciphertexts at scale Delta carries Delta^2; this brings it back (no key involved)."""
+        lo = self.lo
+        self._run("rescale1")
+        self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.B * lo.n, lo.world, lo.rank)
+        self._run("rescale2")

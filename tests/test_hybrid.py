@@ -38,6 +38,8 @@ def _run(vp, n, mods, specials, alpha, ct, key, op, k=0, **kw):
     hs.load_key(key); hs.load_ct(ct)
     if op == "multiply":
         hs.load_ct_b(ct[::-1].copy()); hs.multiply()
+    elif op == "rescale":
+        hs.rescale()
     else:
         hs.rotate(k)
     return hs
@@ -84,6 +86,25 @@ def test_hybrid_rotate_and_multiply_decrypt_correctly(alpha, K):
     got = toy.decrypt(hs.read_out())
     exp = toy.negacyclic(ma, mb)
     assert max(abs(a - b) for a, b in zip(got, exp)) < 1 << 36 and max(abs(x) for x in exp) > 1 << 50
+
+
+def test_rescale_divides_by_the_last_prime_under_decryption():
+    """The leveled-CKKS step after a product: decrypt(rescale(ct)) under q_0..q_{L-2} = round(m / q_{L-1}) up to
+    the rounding noise (a few units times the secret's weight)."""
+    from ckks_toy import ToyCKKS
+    n, L, K = 1024, 4, 2
+    toy, specials = _toy(n, L, K, 31)
+    rng = np.random.default_rng(2)
+    qL = toy.moduli[-1]
+    m = [int(x) * qL + int(y) for x, y in zip(rng.integers(-2 ** 30, 2 ** 30, n), rng.integers(0, 1000, n))]
+    ct = toy.encrypt(m)
+    hs = hybrid.HybridKeySwitch(oracle.OracleVP(spm_rows=1 << 14, ksk_rows=1 << 14), n, toy.moduli, specials, 2)
+    hs.load_ct(ct.reshape(2 * L, n))
+    hs.rescale()
+    low = ToyCKKS(n, toy.moduli[:-1], specials[0], 31)
+    low.s = toy.s
+    got = low.decrypt(hs.read_out()[:, :L - 1])
+    assert max(abs(a - round(x / qL)) for a, x in zip(got, m)) < 64
 
 
 class _RomOnly:
@@ -202,7 +223,7 @@ def _check_sharded(tmp_path, n, L, K, alpha, op, engine):
     assert seen == set(range(L))
 
 
-@pytest.mark.parametrize("op", ["rotate", "multiply"])
+@pytest.mark.parametrize("op", ["rotate", "multiply", "rescale"])
 def test_two_rank_hybrid_gloo(tmp_path, op):
     """L = 5, K = 2, alpha = 2 over two ranks (uneven shards, a special prime on each rank)."""
     _check_sharded(tmp_path, 1024, 5, 2, 2, op, "oracle")
@@ -225,7 +246,7 @@ def test_two_rank_batched_hybrid_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("op", ["rotate", "multiply"])
+@pytest.mark.parametrize("op", ["rotate", "multiply", "rescale"])
 def test_two_rank_hybrid_real_engines(tmp_path, op):
     _check_sharded(tmp_path, 4096, 5, 2, 2, op, "gpu")
 
@@ -245,7 +266,7 @@ def test_hybrid_on_gpu_matches_oracle_and_golden():
     for alpha in (2, 4):
         mods, specials, ct, key = _random_case(n, L, K, alpha, 40 + alpha)
         lo = hybrid.HybridLayout(n, mods, specials, alpha)
-        for op in ("rotate", "multiply"):
+        for op in ("rotate", "multiply", "rescale"):
             k = pow(3, 3, 2 * n)
             exp = _run(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows), n, mods, specials, alpha,
                        ct, key, op, k).read_out()
