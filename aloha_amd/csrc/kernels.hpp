@@ -79,6 +79,7 @@ struct TwiddleDev {
   const u64 *fwd_blk;    // blocked copy for the tile kernels, see ntt_tile.hip
   const u64 *inv_blk;
   u64 n_inv, n_inv_shoup;
+  u64 w1n_inv, w1n_inv_shoup;   // psi^-bitrev(1) * N^-1: twiddle of the last inverse stage with the scaling folded in
 };
 
 // One limb job of a batched transform.  Device job arrays hold 2*count entries: the first

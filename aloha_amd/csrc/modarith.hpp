@@ -103,18 +103,22 @@ ALOHA_DEV u64 shoup_qhat_approx(u64 a, u64 wp) {
 }
 
 // low 64 bits of a*w + b*nq  (nq = 2^64 - q, always wave-uniform): the two 64-bit low
-// products share one accumulator chain, every addition folded into a multiply-add.
+// products share one accumulator chain, every addition folded into a multiply-add; the four
+// cross terms -- of which only the low dword matters -- ride a multiply-add chain of their own
+// (see shoup_fold_add below: an instruction costs one issue slot whatever it computes).
 template <bool UNI>
 ALOHA_DEV u64 mullo2_acc(u64 a, u64 w, u64 b, u64 nq) {
   u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(w), w1 = hi32(w);
   u32 b0 = lo32(b), b1 = hi32(b), n0 = lo32(nq), n1 = hi32(nq);
-  u32 x0 = UNI ? mullo32_s(a1, w0) : mullo32(a1, w0);
-  u32 x1 = UNI ? mullo32_s(a0, w1) : mullo32(a0, w1);
-  u32 x2 = mullo32_s(b1, n0);
-  u32 x3 = mullo32_s(b0, n1);
-  u32 cross = x0 + x1 + x2 + x3;                      // only the low 32 bits matter
-  u64 acc = UNI ? mad32_s(a0, w0, pack64(0, cross)) : mad32(a0, w0, pack64(0, cross));
-  return mad32_s(b0, n0, acc);
+  u64 t = UNI ? mad32_zs(a1, w0) : mad32_z(a1, w0);
+  t = UNI ? mad32_s(a0, w1, t) : mad32(a0, w1, t);
+  t = mad32_s(b1, n0, t);
+  t = mad32_s(b0, n1, t);                                       // lo32(t) = sum of the four cross terms (mod 2^32)
+  u64 acc = UNI ? mad32_zs(a0, w0) : mad32_z(a0, w0);
+  acc = mad32_s(b0, n0, acc);
+  u32 h = hi32(acc);
+  asm("v_add_u32 %0, %0, %1" : "+v"(h) : "v"(lo32(t)));
+  return pack64(lo32(acc), h);
 }
 
 template <bool UNI>
@@ -210,6 +214,17 @@ ALOHA_DEV u64 csub_borrow(u64 x, u64 m) {
   const bool borrow = __builtin_usubll_overflow(x, m, &d);
   return borrow ? x : d;
 }
+// The same, written on the 32-bit halves so that the borrow of the high subtraction itself selects
+// (v_sub_co, v_subb_co, 2 x v_cndmask): from the 64-bit form LLVM re-derives the condition with a
+// separate 64-bit compare.  (Not inline asm: a VALU write of VCC needs two wait states before a VALU
+// read of it on this target, which the compiler only tracks for its own instructions.)
+ALOHA_DEV u64 csub_u(u64 x, u64 m) {
+  u32 dl, dh, t;
+  const bool b1 = __builtin_usub_overflow(lo32(x), lo32(m), &dl);
+  const bool b2 = __builtin_usub_overflow(hi32(x), hi32(m), &t);
+  const bool b3 = __builtin_usub_overflow(t, (u32)b1, &dh);
+  return (b2 | b3) ? x : pack64(dl, dh);
+}
 
 // Canonicalise ANY 64-bit x (used once per element at the end of a pass): estimate
 // k ~ floor(x / q) from the high words, subtract k*q, one conditional subtraction.
@@ -221,7 +236,7 @@ ALOHA_DEV u64 canon_any(u64 x, u64 q, u64 nq, u32 kc) {
   const u32 k = mulhi32_s(hi32(x), kc) >> 27;
   u64 r = mad32_s(k, lo32(nq), x);                       // x + k*nq0 (carry into the high word)
   r = pack64(lo32(r), hi32(r) + mullo32_s(k, hi32(nq)));  // + (k*nq1 << 32)   == x - k*q (mod 2^64)
-  return csub_borrow(r, q);
+  return csub_u(r, q);
 }
 
 // ---- general product of two residues (Barrett, single-word ratio) -----------------------

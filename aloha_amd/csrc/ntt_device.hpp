@@ -80,7 +80,7 @@ __device__ __forceinline__ void fwd_radix16(u64 (&v)[16], const TW &tw, u64 q, u
 #pragma unroll
       for (int jj = 0; jj < half; jj++) {
         const int i0 = g * 2 * half + jj;
-        if (need_corr(B[ss])) v[i0] = csub_borrow(v[i0], q * (u64)corr_t(B[ss]));
+        if (need_corr(B[ss])) v[i0] = csub_u(v[i0], q * (u64)corr_t(B[ss]));
         ct_bfly<UNI, false>(v[i0], v[i0 + half], t.w, t.wp, nq, fourq);
       }
     }
@@ -91,29 +91,132 @@ __device__ __forceinline__ void fwd_radix16(u64 (&v)[16], const TW &tw, u64 q, u
 //   X' = X + Y (- 4q) < 4q,   Y' = (X - Y + 4q) * w  in [0, 4q)   (approximate-quotient Shoup)
 template <bool UNI>
 __device__ __forceinline__ void gs_bfly(u64 &X, u64 &Y, u64 w, u64 wp, u64 nq, u64 fourq) {
-  const u64 s = csub_borrow(X + Y, fourq);
+  const u64 s = csub_u(X + Y, fourq);
   const u64 d = X + fourq - Y;
   Y = mul_shoup_4q<UNI>(d, w, wp, nq);
   X = s;
 }
 
-template <bool UNI, typename TW>
-__device__ __forceinline__ void inv_radix16(u64 (&v)[16], const TW &tw, u64 q, u64 nq) {
-  const u64 fourq = q << 2;
+// ---- lazy ranges of the inverse butterflies -----------------------------------------------------
+// In a GS butterfly only the difference is multiplied (and thereby reduced to < 4q whatever its
+// size); the sum X + Y doubles its bound at every stage.  Instead of one conditional subtract per
+// butterfly (32 per radix-16 step) the sums are left to grow up to 16q and halved -- one
+// borrow-subtract of ceil(b/2)*q takes a bound b to ceil(b/2) -- only where a compile-time plan
+// says the next addition (or the step's output format) needs it: 20 subtracts per step with
+// every input and output of the step < 4q.  Bounds are strict and in units of q, as above.
+//   per butterfly:  [halve X] [halve Y]   S = X + Y   D = X + cq*q - Y   Y' = D*w (< 4q)   [halve S]   X' = S
+// SCALE (the last step of the last pass): the final sub-stage multiplies the sum by N^-1 and the
+// difference by w*N^-1 (both Shoup products: any 64-bit input), which is the reference's
+// halving at every stage (halfred.sv:23-26) collected into one factor; outputs < 4q.
+struct InvPlan {
+  unsigned char hx[4][8][2];   // halving moduli (units of q) applied to X before the sum; 0 = none
+  unsigned char hy[4][8][2];   // ... to Y
+  unsigned char cq[4][8];      // the butterfly's C in units of q (>= bound of Y; bound of X + cq <= 16)
+  unsigned char hs[4][8][3];   // halvings of the sum
+  unsigned char fin[16][3];    // normalisation of the step's outputs to the output bound
+  int subtracts;               // total borrow-subtracts of the step
+  bool ok;
+};
+constexpr int inv_half(int b) { return (b + 1) / 2; }
+constexpr InvPlan inv_plan(int bin, int bout, bool scale) {
+  InvPlan p{};
+  p.ok = true;
+  int b[16] = {};
+  for (int i = 0; i < 16; i++) b[i] = bin;
+  for (int idx = 0; idx < 4; idx++) {
+    const int ss = 3 - idx, half = 8 >> ss;
+    for (int g = 0; g < (1 << ss); g++)
+      for (int jj = 0; jj < half; jj++) {
+        const int k = g * half + jj, i0 = g * 2 * half + jj, i1 = i0 + half;
+        int nx = 0, ny = 0;
+        while (b[i0] + b[i1] > 16) {
+          if (b[i0] >= b[i1]) {
+            if (nx == 2) { p.ok = false; break; }
+            p.hx[idx][k][nx++] = (unsigned char)inv_half(b[i0]);
+            b[i0] = inv_half(b[i0]);
+          } else {
+            if (ny == 2) { p.ok = false; break; }
+            p.hy[idx][k][ny++] = (unsigned char)inv_half(b[i1]);
+            b[i1] = inv_half(b[i1]);
+          }
+          p.subtracts++;
+        }
+        p.cq[idx][k] = (unsigned char)b[i1];
+        int sum = b[i0] + b[i1], ns = 0;
+        if (scale && ss == 0) {
+          sum = 4;
+        } else {
+          while (sum > 8) {
+            if (ns == 3) { p.ok = false; break; }
+            p.hs[idx][k][ns++] = (unsigned char)inv_half(sum);
+            sum = inv_half(sum);
+            p.subtracts++;
+          }
+        }
+        b[i0] = sum;
+        b[i1] = 4;
+      }
+  }
+  for (int i = 0; i < 16; i++) {
+    int nf = 0;
+    while (b[i] > bout) {
+      if (nf == 3) { p.ok = false; break; }
+      p.fin[i][nf++] = (unsigned char)inv_half(b[i]);
+      b[i] = inv_half(b[i]);
+      p.subtracts++;
+    }
+  }
+  return p;
+}
+
+constexpr int INV_IN = 2;    // memory operands: < 2^60 < 2q
+constexpr int INV_MID = 4;   // format between the steps and passes of an inverse transform
+
+// radix-16 inverse step on 16 registers, sub-stages 3..0 (pairs 1, 2, 4, 8 apart).  Inputs < BIN*q,
+// outputs < INV_MID*q (SCALE: < 4q and multiplied by N^-1; `last` = (w, w') of tw(0,0)*N^-1).
+template <bool UNI, int BIN, bool SCALE, typename TW>
+__device__ __forceinline__ void inv_radix16(u64 (&v)[16], const TW &tw, u64 q, u64 nq, tw_t last = tw_t{0, 0},
+                                            u64 ni = 0, u64 nip = 0) {
+  constexpr InvPlan P = inv_plan(BIN, INV_MID, SCALE);
+  static_assert(P.ok, "inverse lazy range plan failed");
 #pragma unroll
-  for (int ss = 3; ss >= 0; ss--) {
-    const int half = 8 >> ss;
+  for (int idx = 0; idx < 4; idx++) {
+    const int ss = 3 - idx, half = 8 >> ss;
 #pragma unroll
     for (int g = 0; g < (1 << ss); g++) {
-      const tw_t t = tw(ss, g);
+      const tw_t t = (SCALE && ss == 0) ? last : tw(ss, g);
 #pragma unroll
       for (int jj = 0; jj < half; jj++) {
-        const int i0 = g * 2 * half + jj;
-        gs_bfly<UNI>(v[i0], v[i0 + half], t.w, t.wp, nq, fourq);
+        const int k = g * half + jj, i0 = g * 2 * half + jj, i1 = i0 + half;
+        u64 X = v[i0], Y = v[i1];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          if (P.hx[idx][k][h]) X = csub_u(X, q * (u64)P.hx[idx][k][h]);
+          if (P.hy[idx][k][h]) Y = csub_u(Y, q * (u64)P.hy[idx][k][h]);
+        }
+        u64 s = X + Y;
+        const u64 d = X + q * (u64)P.cq[idx][k] - Y;
+        v[i1] = mul_shoup_4q<UNI>(d, t.w, t.wp, nq);
+        if (SCALE && ss == 0) {
+          s = mul_shoup_4q<true>(s, ni, nip, nq);
+        } else {
+#pragma unroll
+          for (int h = 0; h < 3; h++)
+            if (P.hs[idx][k][h]) s = csub_u(s, q * (u64)P.hs[idx][k][h]);
+        }
+        v[i0] = s;
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+#pragma unroll
+    for (int h = 0; h < 3; h++)
+      if (P.fin[i][h]) v[i] = csub_u(v[i], q * (u64)P.fin[i][h]);
 }
+
+// [0, 4q) -> [0, q)
+__device__ __forceinline__ u64 canon_4q(u64 x, u64 q) { return csub_u(csub_u(x, q << 1), q); }
 
 // twiddle accessors over one 256-entry block
 __device__ __forceinline__ tw_t load_tw(ctw_t p) {
@@ -164,7 +267,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // (SURVEY A.2).
 __device__ __forceinline__ u64 scale_canon(u64 x, u64 ni, u64 nip, u64 q, u64 nq) {
   const u64 r = mul_shoup_4q<true>(x, ni, nip, nq);          // < 4q
-  return csub_borrow(csub_borrow(r, q << 1), q);
+  return csub_u(csub_u(r, q << 1), q);
 }
 
 // Intermediate formats between the passes of one transform:

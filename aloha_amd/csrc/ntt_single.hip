@@ -106,7 +106,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void ntt_single_kernel(const Limb
 #pragma unroll
       for (int h = 0; h < NH; h++) {
         const tw_t w = load_tw(tab + 4096 + h * T + t);
-        if (need_corr(B3)) v[2 * h] = csub_borrow(v[2 * h], q * (u64)corr_t(B3));
+        if (need_corr(B3)) v[2 * h] = csub_u(v[2 * h], q * (u64)corr_t(B3));
         ct_bfly<false, false>(v[2 * h], v[2 * h + 1], w.w, w.wp, nq, fourq);
       }
     } else if (E == 2) {                                       // stage 12: bit 1 (group e >> 2 = h*T + t); stage 13: bit 0
@@ -115,7 +115,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void ntt_single_kernel(const Limb
         const tw_t w = load_tw(tab + 4096 + h * T + t);
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          if (need_corr(B3)) v[4 * h + j] = csub_borrow(v[4 * h + j], q * (u64)corr_t(B3));
+          if (need_corr(B3)) v[4 * h + j] = csub_u(v[4 * h + j], q * (u64)corr_t(B3));
           ct_bfly<false, false>(v[4 * h + j], v[4 * h + j + 2], w.w, w.wp, nq, fourq);
         }
       }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void ntt_single_kernel(const Limb
 #pragma unroll
         for (int j = 0; j < 2; j++) {                          // group e >> 1 = h*(N/8) + 2t + j
           const tw_t w = load_tw(tab + 8192 + h * (N / 8) + 2 * t + j);
-          if (need_corr(B4)) v[4 * h + 2 * j] = csub_borrow(v[4 * h + 2 * j], q * (u64)corr_t(B4));
+          if (need_corr(B4)) v[4 * h + 2 * j] = csub_u(v[4 * h + 2 * j], q * (u64)corr_t(B4));
           ct_bfly<false, false>(v[4 * h + 2 * j], v[4 * h + 2 * j + 1], w.w, w.wp, nq, fourq);
         }
     }
@@ -157,14 +157,14 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void ntt_single_kernel(const Limb
       }
     }
     exchange(L3, L2, false);
-    inv_radix16<false>(v, TwPlain{tab, 256, a2}, q, nq);                       // stages 11..8
+    inv_radix16<false, E ? INV_MID : INV_IN, false>(v, TwPlain{tab, 256, a2}, q, nq);   // stages 11..8
     exchange(L2, L1, true);
-    inv_radix16<false>(v, TwPlain{tab, 16, a1}, q, nq);                        // stages 7..4
+    inv_radix16<false, INV_MID, false>(v, TwPlain{tab, 16, a1}, q, nq);                // stages 7..4
     exchange(L1, L0, false);
-    inv_radix16<true>(v, TwPlain{tab, 1, 0}, q, nq);                           // stages 3..0
-    const u64 ni = pr->tw.n_inv, nip = pr->tw.n_inv_shoup;
+    inv_radix16<true, INV_MID, true>(v, TwPlain{tab, 1, 0}, q, nq, tw_t{pr->tw.w1n_inv, pr->tw.w1n_inv_shoup},
+                                     pr->tw.n_inv, pr->tw.n_inv_shoup);               // stages 3..0, times N^-1
 #pragma unroll
-    for (int r = 0; r < 16; r++) st_stream(dst + r * T + t, scale_canon(v[r], ni, nip, q, nq));
+    for (int r = 0; r < 16; r++) st_stream(dst + r * T + t, canon_4q(v[r], q));
   }
 }
 

@@ -118,17 +118,17 @@ __global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict_
   } else {
 #pragma unroll
     for (int jj = 0; jj < 16; jj++) v[jj] = ld_stream(&(src + ((size_t)jj << 8))[offB]);
-    inv_radix16<false>(v, TwStepB{blk, (int)slow}, q, nq);               // < 4q throughout
+    inv_radix16<false, FIRST ? INV_IN : INV_MID, false>(v, TwStepB{blk, (int)slow}, q, nq);
 #pragma unroll
     for (int jj = 0; jj < 16; jj++) sdata[col * PITCH + 16 * slow + jj] = v[jj];
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) v[kk] = sdata[col * PITCH + slow + 16 * kk];
-    inv_radix16<true>(v, TwStepA{blk}, q, nq);
-    const u64 ni = pr->tw.n_inv, nip = pr->tw.n_inv_shoup;
+    inv_radix16<true, INV_MID, LAST>(v, TwStepA{blk}, q, nq, tw_t{pr->tw.w1n_inv, pr->tw.w1n_inv_shoup}, pr->tw.n_inv,
+                                     pr->tw.n_inv_shoup);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++)
-      st_stream(&(dst + ((size_t)(16 * kk) << 8))[offA], LAST ? scale_canon(v[kk], ni, nip, q, nq) : v[kk]);
+      st_stream(&(dst + ((size_t)(16 * kk) << 8))[offA], LAST ? canon_4q(v[kk], q) : v[kk]);
   }
 }
 
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void ntt_col_small_kernel(const LimbJob *__res
 #pragma unroll
       for (int i = 0; i < 16; i++) v[i] = sdata[col * PIT + rowB(i)];
       step_b(v, [&](u64 &X, u64 &Y, const tw_t &w, int tt) {
-        if (need_corr(BS[tt])) X = csub_borrow(X, q * (u64)corr_t(BS[tt]));
+        if (need_corr(BS[tt])) X = csub_u(X, q * (u64)corr_t(BS[tt]));
         ct_bfly<false, false>(X, Y, w.w, w.wp, nq, q << 2);
       }, true);
     }
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void ntt_col_small_kernel(const LimbJob *__res
     for (int i = 0; i < 16; i++) {
       u64 x = v[i];
       if (LAST) x = canon_any(x, q, nq, (u32)pr->m.kc);
-      else if (BOUT > FWD_MID) x = csub_borrow(x, q * (u64)corr_t(BOUT));   // the row pass expects < FWD_MID*q
+      else if (BOUT > FWD_MID) x = csub_u(x, q * (u64)corr_t(BOUT));   // the row pass expects < FWD_MID*q
       st_stream(&dst[(size_t)(E ? rowB(i) : rowA(i)) << 8], x);
     }
   } else {
@@ -218,11 +218,12 @@ __global__ __launch_bounds__(256) void ntt_col_small_kernel(const LimbJob *__res
 #pragma unroll
       for (int k = 0; k < 16; k++) v[k] = ld_stream(&src[(size_t)rowA(k) << 8]);
     }
-    inv_radix16<true>(v, TwStepA{blk}, q, nq);
-    const u64 ni = pr->tw.n_inv, nip = pr->tw.n_inv_shoup;
+    // (with E = 0 and FIRST the registers hold memory operands, < 2q < INV_MID*q)
+    inv_radix16<true, INV_MID, LAST>(v, TwStepA{blk}, q, nq, tw_t{pr->tw.w1n_inv, pr->tw.w1n_inv_shoup}, pr->tw.n_inv,
+                                     pr->tw.n_inv_shoup);
 #pragma unroll
     for (int k = 0; k < 16; k++)
-      st_stream(&dst[(size_t)rowA(k) << 8], LAST ? scale_canon(v[k], ni, nip, q, nq) : v[k]);
+      st_stream(&dst[(size_t)rowA(k) << 8], LAST ? canon_4q(v[k], q) : v[k]);
   }
 }
 
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(64) void ntt_row_kernel(const LimbJob *__restrict__
     wave_lds_fence();
 #pragma unroll
     for (int jj = 0; jj < 16; jj++) v[jj] = lds[ldsB + jj];
-    inv_radix16<false>(v, TwStepB{blkB, (int)khB}, q, nq);               // < 4q throughout
+    inv_radix16<false, FIRST ? INV_IN : INV_MID, false>(v, TwStepB{blkB, (int)khB}, q, nq);
   }
   // back to the A mapping: second inverse step / 128-byte-segment stores
 #if ALOHA_ABLATE != 4   // timing experiment 4: skip the transpose back (stores land in the wrong order)
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(64) void ntt_row_kernel(const LimbJob *__restrict__
   for (int kk = 0; kk < 16; kk++) v[kk] = lds[ldsA + 17 * kk];
 #endif
   if (INV) {
-    inv_radix16<UNIA>(v, TwStepA{blkA}, q, nq);
+    inv_radix16<UNIA, INV_MID, false>(v, TwStepA{blkA}, q, nq);
     if (LAST) {
       const u64 ni = pr->tw.n_inv, nip = pr->tw.n_inv_shoup;
 #pragma unroll

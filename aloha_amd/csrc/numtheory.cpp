@@ -92,6 +92,8 @@ bool make_twiddles(uint64_t q, unsigned logn, TwiddleTables *out) {
   }
   out->n_inv = invmod(n % q, q);
   out->n_inv_shoup = shoup(out->n_inv, q);
+  out->w1n_inv = mulmod(out->inv[2], out->n_inv, q);
+  out->w1n_inv_shoup = shoup(out->w1n_inv, q);
   return true;
 }
 

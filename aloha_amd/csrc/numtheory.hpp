@@ -44,6 +44,7 @@ struct TwiddleTables {
   std::vector<uint64_t> inv;   // 2*N words
   uint64_t psi = 0;
   uint64_t n_inv = 0, n_inv_shoup = 0;      // N^-1 mod q (for fused-scaling inverse kernels)
+  uint64_t w1n_inv = 0, w1n_inv_shoup = 0;  // inv[1] * N^-1 mod q: the last inverse stage's one twiddle with the scaling folded in
 };
 bool make_twiddles(uint64_t q, unsigned logn, TwiddleTables *out);
 

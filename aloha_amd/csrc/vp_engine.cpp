@@ -193,6 +193,8 @@ aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
   ps.dev.tw.inv_blk = ps.d_tables + 4 * (size_t)n + blk_words;
   ps.dev.tw.n_inv = tt.n_inv;
   ps.dev.tw.n_inv_shoup = tt.n_inv_shoup;
+  ps.dev.tw.w1n_inv = tt.w1n_inv;
+  ps.dev.tw.w1n_inv_shoup = tt.w1n_inv_shoup;
   const uint32_t idx = (uint32_t)vp->slots.size();
   HIPCK(vp, hipMemcpyAsync(vp->d_primes + idx, &ps.dev, sizeof(PrimeDev), hipMemcpyHostToDevice, vp->stream));
   HIPCK(vp, hipStreamSynchronize(vp->stream));

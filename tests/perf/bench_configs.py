@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timings of BASELINE.json configs 2-5 on ONE GPU (the headline config is bench.py).
 
-    python tools/bench_configs.py > gpurun_out/configs.json
+    python tests/perf/bench_configs.py > gpurun_out/configs.json
 
 Every workload is checked against the oracle on a sample before it is timed.  Numbers go to
 DESIGN.md section 6; they are not the headline metric.
@@ -13,7 +13,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402

@@ -4,7 +4,7 @@ through the C ABI at N = 2^16 on a batch large enough to stream from HBM, timed 
 calls; algorithmic bytes per SURVEY 8d (element-wise .vv 24 N, .vs / vcp / vfqmod / vaut 16 N,
 transforms 16 N, sums (2T+1) 8 N) against the 8 TB/s HBM peak.
 
-    python tools/bench_kernels.py > gpurun_out/kernels.json
+    python tests/perf/bench_kernels.py > gpurun_out/kernels.json
 
 Every workload is checked against the oracle on one limb before it is timed."""
 from __future__ import annotations
@@ -14,7 +14,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
