@@ -260,21 +260,35 @@ class Exchange:
 
     ``tensor_of(vp, row, nwords)`` must return an int64 torch tensor VIEW of engine memory
     (zero copy on the GPU, see ``device_tensor``); ``None`` selects the copy-in/copy-out
-    path through ``vp.read`` / ``vp.write`` used by the CPU tests."""
+    path through ``vp.read`` / ``vp.write`` used by the CPU tests.
 
-    def __init__(self, group=None, tensor_of: Optional[Callable] = None, always: bool = False):
+    ``stream``: the ``torch.cuda.Stream`` the engine was created on (``VP(stream=s.cuda_stream)``).  The
+    collectives are then enqueued stream-ordered -- RCCL waits for the phase's kernels through an event,
+    the next phase's kernels wait for the collective -- and the host never blocks inside a key-switch;
+    without it every exchange is bracketed by host synchronisation.  ``stub`` skips the communication
+    altogether (per-rank timing of a sharded layout on one GPU; results are then meaningless)."""
+
+    def __init__(self, group=None, tensor_of: Optional[Callable] = None, always: bool = False, stream=None,
+                 stub: bool = False):
         self.group = group
         self.tensor_of = tensor_of
         self.always = always          # run the collectives even for world == 1 (single-rank NCCL smoke test)
+        self.stream = stream
+        self.stub = stub
 
     def all_gather(self, vp, row0: int, chunk: int, world: int, rank: int) -> None:
         """All-gather of ``world`` chunks of ``chunk`` words laid out back to back from SPM row ``row0``
         (rank r owns chunk r)."""
-        if world == 1 and not self.always:
+        if (world == 1 and not self.always) or self.stub:
             return
         import torch
         import torch.distributed as dist
         rows = chunk // LANES
+        if self.tensor_of is not None and self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                buf = self.tensor_of(vp, row0, world * chunk)
+                dist.all_gather_into_tensor(buf, buf[rank * chunk:(rank + 1) * chunk].clone(), group=self.group)
+            return
         vp.sync()
         if self.tensor_of is not None:
             buf = self.tensor_of(vp, row0, world * chunk)
@@ -292,12 +306,17 @@ class Exchange:
         self.all_gather(vp, lo.row(lo.dig), lo.Dr * lo.n, lo.world, lo.rank)
 
     def broadcast_terms(self, vp, lo: Layout) -> None:
-        if lo.world == 1 and not self.always:
+        if (lo.world == 1 and not self.always) or self.stub:
             return
         import torch
         import torch.distributed as dist
         src = owner(lo.L, lo.world)
         row = lo.row(lo.t)
+        if self.tensor_of is not None and self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                dist.broadcast(self.tensor_of(vp, row, 2 * lo.n),
+                               src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+            return
         vp.sync()
         if self.tensor_of is not None:
             buf = self.tensor_of(vp, row, 2 * lo.n)

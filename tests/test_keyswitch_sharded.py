@@ -252,6 +252,19 @@ def test_streamed_keyswitch_on_gpu_n65536():
             ks.load_key(ksk); ks.load_ct(ct)
             ks.rotate(k)
             assert np.array_equal(ks.read_out(), exp)
+            # ... and stream-ordered: the engine runs on a torch stream, the collectives are enqueued on it
+            # and the host never blocks between the phases of a key-switch
+            st = torch.cuda.Stream()
+            with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16,
+                        stream=st.cuda_stream) as vps:
+                ks = keyswitch.ShardedKeySwitch(vps, n, mods, special, world=1, rank=0,
+                                                exchange=keyswitch.Exchange(tensor_of=keyswitch.device_tensor, always=True,
+                                                                            stream=st))
+                ks.load_key(ksk); ks.load_ct(ct)
+                for _ in range(3):                                   # repeated: a missing ordering edge would show as a race
+                    ks.load_ct(ct)
+                    ks.rotate(k)
+                assert np.array_equal(ks.read_out(), exp)
         finally:
             dist.destroy_process_group()
     m = manifest()["case0"]

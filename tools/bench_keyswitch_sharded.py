@@ -36,13 +36,20 @@ def main() -> int:
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--verify", action="store_true")
+    ap.add_argument("--batch", type=int, default=1, help="ciphertexts per call (hybrid only)")
+    ap.add_argument("--host-sync", action="store_true", help="bracket every exchange with host synchronisation (the old path)")
+    ap.add_argument("--stub-world", type=int, default=0,
+                    help="time rank 0's share of a W-rank layout on this one GPU with the exchanges skipped (results meaningless)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if args.stub_world:
+        assert world == 1 and not args.verify
+        world = args.stub_world
     local = int(os.environ.get("ALOHA_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     backend = os.environ.get("ALOHA_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 and not args.stub_world:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -54,15 +61,17 @@ def main() -> int:
     mods = [avp.nth_prime(logn, i) for i in range(L)]
     K = max(1, args.alpha)
     specials = [avp.nth_prime(logn, L + k) for k in range(K)]
-    ex = keyswitch.Exchange(tensor_of=keyswitch.device_tensor if backend == "nccl" else None, always=False)
+    stream = torch.cuda.Stream()
+    ex = keyswitch.Exchange(tensor_of=keyswitch.device_tensor if backend == "nccl" else None, always=False,
+                            stream=None if (args.host_sync or backend != "nccl") else stream, stub=bool(args.stub_world))
 
     def build(vp, w, r, exch):
         if args.alpha == 0:
             return keyswitch.ShardedKeySwitch(vp, n, mods, specials[0], world=w, rank=r, exchange=exch)
-        return hybrid.HybridKeySwitch(vp, n, mods, specials, args.alpha, world=w, rank=r, exchange=exch)
+        return hybrid.HybridKeySwitch(vp, n, mods, specials, args.alpha, world=w, rank=r, exchange=exch, batch=args.batch)
 
     def layout(w, r):
-        return keyswitch.Layout(n, mods, specials[0], w, r) if args.alpha == 0 else hybrid.HybridLayout(n, mods, specials, args.alpha, w, r)
+        return keyswitch.Layout(n, mods, specials[0], w, r) if args.alpha == 0 else hybrid.HybridLayout(n, mods, specials, args.alpha, w, r, batch=args.batch)
 
     def load(ks, lo, seed=7):
         """Same pseudo-random ciphertexts and key on every rank count: limb contents depend on the limb only."""
@@ -72,10 +81,15 @@ def main() -> int:
             rng = np.random.default_rng(seed * 1000 + j)
             ks.vp.write(1, jl * digits * 2 * lo.rows, rng.integers(0, all_mods[j], digits * 2 * n, dtype=np.uint64))
         ct = np.stack([np.random.default_rng(seed * 77 + j).integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
-        ks.load_ct(ct); ks.load_ct_b(ct[::-1].copy())
+        if args.alpha == 0:
+            ks.load_ct(ct); ks.load_ct_b(ct[::-1].copy())
+        else:
+            for b in range(args.batch):
+                ks.load_ct(ct, b); ks.load_ct_b(ct[::-1].copy(), b)
 
     lo = layout(world, rank)
-    vp = avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=max(1, lo.ksk_limbs * lo.rows), max_log_n=logn, device=local)
+    vp = avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=max(1, lo.ksk_limbs * lo.rows), max_log_n=logn, device=local,
+                stream=stream.cuda_stream)
     ks = build(vp, world, rank, ex)
     load(ks, lo)
     k = pow(3, 5, 2 * n)
@@ -88,6 +102,7 @@ def main() -> int:
 
     op(); vp.sync()
     barrier()
+    launches0 = vp.stats()["kernel_launches"]
     t0 = time.perf_counter()
     for _ in range(args.reps):
         op()
@@ -114,6 +129,9 @@ def main() -> int:
             ok = bool(t[0] > 0.5)
     if rank == 0:
         print(json.dumps({"metric": f"{args.op} + key-switch at N=2^{logn}", "L": L, "alpha": args.alpha, "K": K, "n_gpus": world,
+                          "batch": args.batch, "exchange": "stubbed (rank 0's share only)" if args.stub_world else
+                          ("host-synchronised" if ex.stream is None else "stream-ordered"),
+                          "launches_per_op": (vp.stats()["kernel_launches"] - launches0) / args.reps,
                           "ms": elapsed / args.reps * 1e3, "ops_per_s": args.reps / elapsed, "backend": backend,
                           "verified_against_single_rank": ok}))
     vp.close()
