@@ -37,6 +37,10 @@ one relinearisation key, or B ciphertexts rotated by the same step): every loop 
 then covers B times as many limbs, which is what fills the chip when the limbs are spread over 8
 ranks (3-4 moduli each) -- the launch count per call does not change.
 
+``hoist()`` + ``rotate_hoisted(k, index)`` rotate one ciphertext by many steps off a single decomposition
+(phases 1-2a once; per step phases 2b-4 with the key stored under sigma_k^-1 and the automorphism applied to
+the two results): see ``load_key_hoisted``.
+
 ``rescale()`` is the leveled-CKKS step after a product, in the same style: the owner of q_{L-1}
 publishes v_c = iNTT(c_c[L-1]) + floor(q_{L-1}/2) (one all-gather of 2B limbs), every rank then
 forms out_c[j] = (c_c[j] - NTT_j(v_c - floor(q_{L-1}/2) mod q_j)) * q_{L-1}^-1 mod q_j for its
@@ -57,6 +61,24 @@ def _prod(xs):
     for x in xs:
         p *= int(x)
     return p
+
+
+def _bitrev(x: np.ndarray, bits: int) -> np.ndarray:
+    r = np.zeros_like(x)
+    for b in range(bits):
+        r |= ((x >> b) & 1) << (bits - 1 - b)
+    return r
+
+
+def ntt_automorphism_gather(n: int, k: int) -> np.ndarray:
+    """``src`` with  sigma_k(x) in NTT form [j] == x in NTT form [src[j]]  for odd k in [0, 2n): position j of a
+    vntt result holds x(psi^(2*brv(j)+1)) and sigma_k(x)(psi^e) = x(psi^(e*k)) (the map of the ``vautn``
+    instruction, without its reduction of k to log2 n bits)."""
+    assert k & 1
+    bits = n.bit_length() - 1
+    j = np.arange(n, dtype=np.int64)
+    e = ((2 * _bitrev(j, bits) + 1) * int(k)) % (2 * n)
+    return _bitrev((e - 1) >> 1, bits)
 
 
 class HybridLayout:
@@ -179,7 +201,7 @@ def blocks_phase1(lo: HybridLayout, mode: str) -> List[List[str]]:
                 b.append(_setq(lo.moduli[j]) + [
                     f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{o(lo.s_rot(i, bi)):#x}",
                     f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{o(lo.s_x(i, bi)):#x}"])
-    else:                                                       # tensor product
+    elif mode == "multiply":                                    # tensor product
         for i, j in own:
             for bi in B:
                 b.append(_setq(lo.moduli[j]) + [
@@ -193,10 +215,11 @@ def blocks_phase1(lo: HybridLayout, mode: str) -> List[List[str]]:
                     f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(1, i, bi)):#x}", "vfqmul.vv v6, v0, v1",
                     f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(0, i, bi)):#x}", "vfqmul.vv v3, v0, v1",
                     "vfqadd.vv v6, v6, v3", f"vse v6, abs+{o(lo.s_base1(i, bi)):#x}"])
+    x_of = (lambda i, bi: lo.s_in(1, i, bi)) if mode == "hoist" else lo.s_x    # hoisted: c1 itself, not rotated
     for i, j in own:                                            # coefficient form
         blk = _setq(lo.moduli[j])
         for bi in B:
-            blk += [f"vle v0, abs+{o(lo.s_x(i, bi)):#x}", "vintt v2, v0", f"vse v2, abs+{o(lo.s_s1(0, i, bi)):#x}"]
+            blk += [f"vle v0, abs+{o(x_of(i, bi)):#x}", "vintt v2, v0", f"vse v2, abs+{o(lo.s_s1(0, i, bi)):#x}"]
         b.append(blk)
     for i, j in own:                                            # times (Q_d/q_j)^-1 mod q_j
         q = lo.moduli[j]
@@ -233,15 +256,16 @@ def blocks_modup(lo: HybridLayout) -> List[List[str]]:
     return b
 
 
-def blocks_inner(lo: HybridLayout) -> List[List[str]]:
+def blocks_inner(lo: HybridLayout, hoisted: bool = False) -> List[List[str]]:
     b, o = [], lo.off
+    x_of = (lambda i, bi: lo.s_in(1, i, bi)) if hoisted else lo.s_x
     for jl, j in enumerate(lo.owned_all):
         for bi in range(lo.B):
             blk = _setq(lo.mods_all[j])
             for c in range(2):
                 acc = 6 + 2 * c
                 for d in range(lo.dnum):
-                    src = o(lo.s_x(lo.owned_ct.index(j), bi)) if j in lo.digit(d) else o(lo.s_sd(jl, d, bi))
+                    src = o(x_of(lo.owned_ct.index(j), bi)) if j in lo.digit(d) else o(lo.s_sd(jl, d, bi))
                     blk += [f"vle v0, abs+{src:#x}", f"vle v1, ksk+{((jl * lo.dnum + d) * 2 + c) * 8 * lo.n:#x}"]
                     blk += [f"vfqmul.vv v{acc}, v0, v1"] if d == 0 else ["vfqmul.vv v3, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v3"]
                 blk.append(f"vse v{acc}, abs+{o(lo.s_acc(jl, c, bi)):#x}")
@@ -270,9 +294,10 @@ def blocks_moddown_terms(lo: HybridLayout) -> List[List[str]]:
     return b
 
 
-def blocks_finish(lo: HybridLayout, add_base1: bool) -> List[List[str]]:
+def blocks_finish(lo: HybridLayout, add_base1: bool, hoisted: bool = False) -> List[List[str]]:
     """t = sum_k W_k * (P/p_k mod q_j) - floor(P/2)  (one fused sum), NTT, then
-    out_c = acc_c * P^-1 + t_c * (-P^-1) + base_c  (one fused sum): two launches besides the transform."""
+    out_c = acc_c * P^-1 + t_c * (-P^-1) + base_c  (one fused sum): two launches besides the transform.
+    ``hoisted``: base_0 is the unrotated c0 and the automorphism (vautn, CSR step) is applied to both results last."""
     b, o, B = [], lo.off, range(lo.B)
     own = list(enumerate(lo.owned_ct))
     for i, j in own:                                            # P-basis -> q_j, minus the rounding offset
@@ -297,10 +322,17 @@ def blocks_finish(lo: HybridLayout, add_base1: bool) -> List[List[str]]:
                 srcs = [o(lo.s_acc(jl, c, bi)), o(lo.s_s2(c, i, bi))]
                 scal = [pinv, q - pinv]
                 if c == 0:
-                    srcs.append(o(lo.s_rot(i, bi))); scal.append(1)
+                    srcs.append(o(lo.s_in(0, i, bi) if hoisted else lo.s_rot(i, bi))); scal.append(1)
                 elif add_base1:
                     srcs.append(o(lo.s_base1(i, bi))); scal.append(1)
-                b.append(_setq(q) + _scalar_sum(srcs, scal, o(lo.s_out(c, i, bi))))
+                b.append(_setq(q) + _scalar_sum(srcs, scal, o(lo.s_s1(c, i, bi) if hoisted else lo.s_out(c, i, bi))))
+    if hoisted:
+        for i, j in own:
+            blk = _setq(lo.moduli[j])
+            for c in range(2):
+                for bi in B:
+                    blk += [f"vle v0, abs+{o(lo.s_s1(c, i, bi)):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{o(lo.s_out(c, i, bi)):#x}"]
+            b.append(blk)
     return b
 
 
@@ -367,6 +399,10 @@ class HybridKeySwitch:
             "terms": asm(_pack(blocks_moddown_terms(lo), n)) if lo.owned_sp else [],
             "fin_rot": asm(_pack(blocks_finish(lo, False), n)) if lo.Lr else [],
             "fin_mul": asm(_pack(blocks_finish(lo, True), n)) if lo.Lr else [],
+            "hoist1": asm(_pack(blocks_phase1(lo, "hoist"), n)) if lo.Lr else [],
+            "modup": asm(_pack(blocks_modup(lo), n)) if lo.Mr else [],
+            "inner_h": asm(_pack(blocks_inner(lo, True), n)) if lo.Mr else [],
+            "fin_h": asm(_pack(blocks_finish(lo, False, True), n)) if lo.Lr else [],
         }
         rs = blocks_rescale(lo)
         self._p["rescale1"] = asm(_pack(rs[0], n)) if rs[0] else []
@@ -414,14 +450,14 @@ class HybridKeySwitch:
         return out
 
     # -- the ops ----------------------------------------------------------------------------------
-    def _run(self, name: str, step: int = 0) -> None:
+    def _run(self, name: str, step: int = 0, ksk: int = 0) -> None:
         for idx, words in enumerate(self._p[name]):
             if self._resident:
                 pc = self._pc[(name, idx)]
             else:
                 pc = 0
                 self.vp.load_isram(0, words)
-            rc = self.vp.run(pc, src0=0, src1=0, rslt=0, ksk=0, step=step)
+            rc = self.vp.run(pc, src0=0, src1=0, rslt=0, ksk=ksk, step=step)
             if rc:
                 raise RuntimeError(f"hybrid key-switch phase {name}[{idx}] failed with status {rc}: "
                                    f"{getattr(self.vp, 'last_error', '')}")
@@ -441,6 +477,40 @@ class HybridKeySwitch:
     def multiply(self) -> None:
         self._run("mul1")
         self._switch("fin_mul")
+
+    # -- hoisted rotations: one decomposition, many steps -------------------------------------------------
+    def load_key_hoisted(self, key_full: np.ndarray, k: int, index: int) -> None:
+        """Key for the rotation by ``k`` (same layout as ``load_key``) into key region ``index``, stored as
+        sigma_k^-1(KEY): then  sum_d sigma_k(SD_d) (.) KEY_d == sigma_k( sum_d SD_d (.) sigma_k^-1(KEY_d) )  and the
+        automorphism moves from the dnum*(L+K) digit limbs to the two results.  In NTT form sigma is a pure
+        permutation of positions, so this is an identity on the stored words."""
+        lo = self.lo
+        src = ntt_automorphism_gather(lo.n, pow(int(k), -1, 2 * lo.n))
+        kf = np.ascontiguousarray(key_full, dtype=np.uint64).reshape(lo.L + lo.K, lo.dnum * 2, lo.n)
+        for jl, j in enumerate(lo.owned_all):
+            self.vp.write(KSK, index * self.key_rows + jl * lo.dnum * 2 * lo.rows, kf[j][:, src].reshape(-1))
+
+    @property
+    def key_rows(self) -> int:
+        return self.lo.ksk_limbs * self.lo.rows
+
+    def hoist(self) -> None:
+        """Decompose c1 of CT_IN once: digits to coefficient form, all-gather, ModUp, back to NTT form (SD).
+        Every ``rotate_hoisted`` afterwards reuses SD: dnum*(L+K) - ... transforms are paid once per ciphertext
+        instead of once per rotation."""
+        lo = self.lo
+        self._run("hoist1")
+        self.ex.all_gather(self.vp, lo.row(lo.y), lo.Yr * lo.B * lo.n, lo.world, lo.rank)
+        self._run("modup")
+
+    def rotate_hoisted(self, k: int, index: int) -> None:
+        """OUT = rotation of CT_IN by ``k`` with the key in region ``index`` (``load_key_hoisted``), after ``hoist()``:
+        inner products on the unrotated digits, mod-down, automorphism of the two result polynomials."""
+        lo = self.lo
+        self._run("inner_h", ksk=index * self.key_rows)
+        self._run("terms")
+        self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.B * lo.n, lo.world, lo.rank)
+        self._run("fin_h", step=k)
 
     def rescale(self) -> None:
         """CT_IN (L limbs) -> OUT (limbs 0 .. L-2 valid): divide by the last ciphertext prime, rounding.

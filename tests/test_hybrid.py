@@ -40,6 +40,9 @@ def _run(vp, n, mods, specials, alpha, ct, key, op, k=0, **kw):
         hs.load_ct_b(ct[::-1].copy()); hs.multiply()
     elif op == "rescale":
         hs.rescale()
+    elif op == "hoisted":                                       # the same key bits serve as "the key of step k" and of step 3k
+        hs.load_key_hoisted(key, k, 0); hs.load_key_hoisted(key, 3 * k % (2 * n), 1)
+        hs.hoist(); hs.rotate_hoisted(k, 0); hs.rotate_hoisted(3 * k % (2 * n), 1)
     else:
         hs.rotate(k)
     return hs
@@ -86,6 +89,55 @@ def test_hybrid_rotate_and_multiply_decrypt_correctly(alpha, K):
     got = toy.decrypt(hs.read_out())
     exp = toy.negacyclic(ma, mb)
     assert max(abs(a - b) for a, b in zip(got, exp)) < 1 << 36 and max(abs(x) for x in exp) > 1 << 50
+
+
+def test_key_stored_under_inverse_automorphism_moves_sigma_out_of_the_inner_product():
+    """The identity hoisting rests on, on stored words: vautn_k(a) (.) b == vautn_k(a (.) gather(b, k^-1)) -- in NTT
+    form the automorphism is a permutation of positions, so it commutes with the pointwise product exactly."""
+    n = 1024
+    q = oracle.nth_prime(10, 0)
+    rng = np.random.default_rng(4)
+    a, b = rng.integers(0, q, n, dtype=np.uint64), rng.integers(0, q, n, dtype=np.uint64)
+    for k in (3, pow(3, 5, 2 * n), 2 * n - 1):
+        if k >= n:                                               # the instruction keeps log2 n bits of the step
+            continue
+        src_inv = hybrid.ntt_automorphism_gather(n, pow(k, -1, 2 * n))
+        assert np.array_equal(oracle.vautn(a, k), a[hybrid.ntt_automorphism_gather(n, k)])
+        mul = lambda x, y: np.array([int(u) * int(v) % q for u, v in zip(x, y)], dtype=np.uint64)
+        assert np.array_equal(mul(oracle.vautn(a, k), b), oracle.vautn(mul(a, b[src_inv]), k))
+
+
+def _hoisted(vp, n, mods, specials, alpha, ct, keys, steps, **kw):
+    """hoist() once, then every step with its own pre-permuted key region; returns the outputs in order."""
+    hs = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha, **kw)
+    for idx, (k, key) in enumerate(zip(steps, keys)):
+        hs.load_key_hoisted(key, k, idx)
+    hs.load_ct(ct)
+    hs.hoist()
+    outs = []
+    for idx, k in enumerate(steps):
+        hs.rotate_hoisted(k, idx)
+        outs.append(hs.read_out())
+    return outs
+
+
+@pytest.mark.parametrize("alpha,K", [(2, 2), (3, 3)])
+def test_hoisted_rotations_decrypt_correctly(alpha, K):
+    """One decomposition, three rotation steps, each with its own key: every output decrypts to the rotated
+    message (exact integers).  Not bit-identical to rotate(): the fast basis conversion does not commute with
+    the sign flips of the automorphism (multiples of Q_d the key cancels), which is why this is a semantic test."""
+    n, L = 1024, 4
+    toy, specials = _toy(n, L, K, 17)
+    rng = np.random.default_rng(9)
+    m = [int(x) << 30 for x in rng.integers(-1000, 1000, n)]
+    ct = toy.encrypt(m).reshape(2 * L, n)
+    steps = [pow(3, r, 2 * n) for r in (1, 4, 6)]
+    assert all(k < n for k in steps)
+    keys = [toy.switch_key_hybrid(toy.automorph(toy.s, k), specials, alpha) for k in steps]
+    outs = _hoisted(oracle.OracleVP(spm_rows=1 << 14, ksk_rows=1 << 15), n, toy.moduli, specials, alpha, ct, keys, steps)
+    for k, out in zip(steps, outs):
+        got, exp = toy.decrypt(out), toy.automorph(m, k)
+        assert max(abs(a - b) for a, b in zip(got, exp)) < 1 << 22
 
 
 def test_rescale_divides_by_the_last_prime_under_decryption():
@@ -223,7 +275,7 @@ def _check_sharded(tmp_path, n, L, K, alpha, op, engine):
     assert seen == set(range(L))
 
 
-@pytest.mark.parametrize("op", ["rotate", "multiply", "rescale"])
+@pytest.mark.parametrize("op", ["rotate", "multiply", "rescale", "hoisted"])
 def test_two_rank_hybrid_gloo(tmp_path, op):
     """L = 5, K = 2, alpha = 2 over two ranks (uneven shards, a special prime on each rank)."""
     _check_sharded(tmp_path, 1024, 5, 2, 2, op, "oracle")
@@ -246,7 +298,7 @@ def test_two_rank_batched_hybrid_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("op", ["rotate", "multiply", "rescale"])
+@pytest.mark.parametrize("op", ["rotate", "multiply", "rescale", "hoisted"])
 def test_two_rank_hybrid_real_engines(tmp_path, op):
     _check_sharded(tmp_path, 4096, 5, 2, 2, op, "gpu")
 
@@ -266,11 +318,11 @@ def test_hybrid_on_gpu_matches_oracle_and_golden():
     for alpha in (2, 4):
         mods, specials, ct, key = _random_case(n, L, K, alpha, 40 + alpha)
         lo = hybrid.HybridLayout(n, mods, specials, alpha)
-        for op in ("rotate", "multiply", "rescale"):
+        for op in ("rotate", "multiply", "rescale", "hoisted"):
             k = pow(3, 3, 2 * n)
-            exp = _run(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows), n, mods, specials, alpha,
+            exp = _run(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=2 * lo.ksk_limbs * lo.rows), n, mods, specials, alpha,
                        ct, key, op, k).read_out()
-            with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
+            with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=2 * lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
                 got = _run(vp, n, mods, specials, alpha, ct, key, op, k).read_out()
             assert np.array_equal(got, exp), (alpha, op)
     # two ciphertexts per call on the GPU == the oracle machine

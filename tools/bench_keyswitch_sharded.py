@@ -32,7 +32,8 @@ def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--L", type=int, default=24)
     ap.add_argument("--alpha", type=int, default=4)
-    ap.add_argument("--op", choices=["rotate", "multiply"], default="multiply")
+    ap.add_argument("--op", choices=["rotate", "multiply", "hoisted"], default="multiply")
+    ap.add_argument("--rotations", type=int, default=8, help="--op hoisted: rotation steps per decomposition (one key each)")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--verify", action="store_true")
@@ -79,7 +80,9 @@ def main() -> int:
         digits = L if args.alpha == 0 else lo.dnum
         for jl, j in enumerate(lo.owned_all):
             rng = np.random.default_rng(seed * 1000 + j)
-            ks.vp.write(1, jl * digits * 2 * lo.rows, rng.integers(0, all_mods[j], digits * 2 * n, dtype=np.uint64))
+            kl = rng.integers(0, all_mods[j], digits * 2 * n, dtype=np.uint64)
+            for r in range(nkeys):                                # (the same words serve as every rotation's key: timing only)
+                ks.vp.write(1, (r * lo.Mr * digits + jl * digits) * 2 * lo.rows, kl)
         ct = np.stack([np.random.default_rng(seed * 77 + j).integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
         if args.alpha == 0:
             ks.load_ct(ct); ks.load_ct_b(ct[::-1].copy())
@@ -87,13 +90,21 @@ def main() -> int:
             for b in range(args.batch):
                 ks.load_ct(ct, b); ks.load_ct_b(ct[::-1].copy(), b)
 
+    nkeys = args.rotations if args.op == "hoisted" else 1
+    assert args.op != "hoisted" or args.alpha > 0
     lo = layout(world, rank)
-    vp = avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=max(1, lo.ksk_limbs * lo.rows), max_log_n=logn, device=local,
+    vp = avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=max(1, nkeys * lo.ksk_limbs * lo.rows), max_log_n=logn, device=local,
                 stream=stream.cuda_stream)
     ks = build(vp, world, rank, ex)
     load(ks, lo)
     k = pow(3, 5, 2 * n)
-    op = (lambda: ks.rotate(k)) if args.op == "rotate" else ks.multiply
+    steps = [pow(3, r + 1, 2 * n) for r in range(nkeys)]
+
+    def hoisted():
+        ks.hoist()
+        for r, kr in enumerate(steps):
+            ks.rotate_hoisted(kr, r)
+    op = (lambda: ks.rotate(k)) if args.op == "rotate" else (hoisted if args.op == "hoisted" else ks.multiply)
 
     def barrier():
         if dist.is_initialized() and world > 1:
@@ -106,6 +117,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for _ in range(args.reps):
         op()
+    enqueue = time.perf_counter() - t0                          # host time to issue everything (the GPU may lag behind)
     vp.sync()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -117,10 +129,11 @@ def main() -> int:
     ok = None
     if args.verify:                                              # every rank: its owned limbs == a single-rank engine's
         lo1 = layout(1, 0)
-        with avp.VP(spm_rows=lo1.spm_rows_needed, ksk_rows=lo1.ksk_limbs * lo1.rows, max_log_n=logn, device=local) as vp1:
+        with avp.VP(spm_rows=lo1.spm_rows_needed, ksk_rows=nkeys * lo1.ksk_limbs * lo1.rows, max_log_n=logn, device=local) as vp1:
             ks1 = build(vp1, 1, 0, keyswitch.Exchange())
             load(ks1, lo1)
-            (ks1.rotate(k) if args.op == "rotate" else ks1.multiply())
+            (ks1.rotate(k) if args.op == "rotate" else (ks1.multiply() if args.op == "multiply" else
+                                                         (ks1.hoist(), [ks1.rotate_hoisted(kr, r) for r, kr in enumerate(steps)])))
             ref = ks1.read_out()
         ok = all(np.array_equal(out[:, i], ref[:, j]) for i, j in enumerate(lo.owned_ct))
         if dist.is_initialized() and world > 1:
@@ -132,7 +145,8 @@ def main() -> int:
                           "batch": args.batch, "exchange": "stubbed (rank 0's share only)" if args.stub_world else
                           ("host-synchronised" if ex.stream is None else "stream-ordered"),
                           "launches_per_op": (vp.stats()["kernel_launches"] - launches0) / args.reps,
-                          "ms": elapsed / args.reps * 1e3, "ops_per_s": args.reps / elapsed, "backend": backend,
+                          "rotations_per_call": nkeys, "ms_per_rotation": elapsed / args.reps * 1e3 / nkeys,
+                          "ms": elapsed / args.reps * 1e3, "host_enqueue_ms": enqueue / args.reps * 1e3, "ops_per_s": args.reps / elapsed, "backend": backend,
                           "verified_against_single_rank": ok}))
     vp.close()
     if dist.is_initialized():
