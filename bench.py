@@ -36,7 +36,7 @@ import torch  # noqa: E402
 LOGN = 16
 N = 1 << LOGN
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = "r01_l_pmc_summary.json"   # written by tools/collect_pmc.sh for the kernels of this commit
+PMC_SUMMARY = "r01_s_pmc_summary.json"   # written by tools/collect_pmc.sh for the kernels of this commit
 
 
 def measured_traffic_per_step(limbs: int):
