@@ -334,3 +334,35 @@ def test_hybrid_on_gpu_matches_oracle_and_golden():
         got = _run_batch(vp, n, mods, specials, 4, cts, key, "multiply")
         for b in range(2):
             assert np.array_equal(got.read_out(b), ref.read_out(b)), b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,op", [(24, "multiply"), (32, "rotate")])
+def test_baseline_configs_4_and_5_at_full_size_gpu_equals_oracle_machine(L, op):
+    """BASELINE config 4 (HMult + relinearisation, N = 2^16, 24 limbs) and config 5 (rotate + key-switch, 32 limbs)
+    at their full sizes, hybrid alpha = 4, K = 4: every owned output word of the GPU == the oracle's ISA machine
+    running the same programs (the oracle needs a few seconds per key-switch at this size)."""
+    from aloha_amd import vp as avp
+    n, K, alpha = 1 << 16, 4, 4
+    mods, specials = _setup(n, L, K, 0)
+    lo = hybrid.HybridLayout(n, mods, specials, alpha)
+    rng = np.random.default_rng(100 + L)
+    ct = np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
+    k = pow(3, 5, 2 * n)
+
+    def run(vp):
+        hs = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha)
+        for jl, j in enumerate(lo.owned_all):                    # key limb by limb (a whole key is 168-288 MiB)
+            vp.write(keyswitch.KSK, jl * lo.dnum * 2 * lo.rows,
+                     np.random.default_rng(7000 + j).integers(0, lo.mods_all[j], lo.dnum * 2 * n, dtype=np.uint64))
+        hs.load_ct(ct)
+        if op == "multiply":
+            hs.load_ct_b(ct[::-1].copy()); hs.multiply()
+        else:
+            hs.rotate(k)
+        return hs.read_out()
+
+    exp = run(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows))
+    with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
+        got = run(vp)
+    assert np.array_equal(got, exp)

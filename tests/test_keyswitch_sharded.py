@@ -272,3 +272,31 @@ def test_streamed_keyswitch_on_gpu_n65536():
         got = _single_rank(vp, N, [Q0, Q1], P, load(m["kernel1_ct_before_rotate"]).reshape(4, N), load(m["ksk_step2"]),
                            pow(3, 2, 2 * N))
     assert np.array_equal(got, load(m["kernel1_ct_after_rotate"]).reshape(2, 2, N))
+
+
+@pytest.mark.gpu
+def test_baseline_config4_full_size_reference_algorithm_gpu_equals_oracle_machine():
+    """BASELINE config 4 as SURVEY 8d states it: HMult + relinearisation at N = 2^16, L = 24 (+1 special prime),
+    one digit per prime (the reference's decomposition, 1200 key limbs): GPU == the oracle's ISA machine on every
+    output word.  (The oracle takes ~20 s for the 674 transforms.)"""
+    from aloha_amd import vp as avp
+    n, L = 1 << 16, 24
+    mods = [oracle.nth_prime(16, i) for i in range(L)]
+    special = oracle.nth_prime(16, L)
+    lo = keyswitch.Layout(n, mods, special)
+    rng = np.random.default_rng(24)
+    ct = np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
+
+    def run(vp):
+        ks = keyswitch.ShardedKeySwitch(vp, n, mods, special)
+        for jl, j in enumerate(lo.owned_all):                    # key limb group by group (600 MiB in all)
+            vp.write(keyswitch.KSK, jl * L * 2 * lo.rows,
+                     np.random.default_rng(9000 + j).integers(0, lo.modulus(j), L * 2 * n, dtype=np.uint64))
+        ks.load_ct(ct); ks.load_ct_b(ct[::-1].copy())
+        ks.multiply()
+        return ks.read_out()
+
+    exp = run(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows))
+    with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
+        got = run(vp)
+    assert np.array_equal(got, exp)
