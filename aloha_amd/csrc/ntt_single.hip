@@ -61,8 +61,11 @@ struct TwPlain {
   __device__ __forceinline__ tw_t operator()(int ss, int g) const { return load_tw(tab + (base << ss) + (a << ss) + g); }
 };
 
+#ifndef ALOHA_SINGLE_WAVES
+#define ALOHA_SINGLE_WAVES 4   // at least 4 waves per SIMD (<= 128 VGPRs): two workgroups per CU at N = 2^13
+#endif
 template <int LOGN, bool INV>
-__global__ __launch_bounds__((1 << LOGN) / 16) void ntt_single_kernel(const LimbJob *__restrict__ jobs,
+__global__ __launch_bounds__((1 << LOGN) / 16) __attribute__((amdgpu_waves_per_eu(ALOHA_SINGLE_WAVES))) void ntt_single_kernel(const LimbJob *__restrict__ jobs,
                                                                        const PrimeDev *__restrict__ primes) {
   constexpr int N = 1 << LOGN, T = N / 16, E = LOGN - 12, NH = 16 >> E;     // NH = groups of 2^E registers in L3
   extern __shared__ __attribute__((aligned(16))) u64 lds[];

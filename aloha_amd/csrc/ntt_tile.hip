@@ -33,7 +33,9 @@
 //
 // Arithmetic: lazy, see modarith.hpp.  Forward: relaxed CT butterflies with approximate Shoup
 // quotients, values < 16q, borrow-subtracts placed by a compile-time range plan.  Inverse:
-// Harvey GS butterflies, values < 4q, N^-1 fused into the last pass.  HBM traffic per pass:
+// GS butterflies whose sums grow lazily up to 16q on a compile-time plan of their own (inv_plan,
+// ntt_device.hpp), < 4q between steps and passes, N^-1 folded into the two products of the last
+// stage.  HBM traffic per pass:
 // read + write of the limb (+ twiddle blocks); algorithmic bytes per transform: 16*N
 // (SURVEY 8d).  Timing experiments (ALOHA_ABLATE builds, profiles/): memory skeleton ~195 us
 // per pass per 1024 limbs, arithmetic ~150-180 us; in the row pass the transpose-back costs
@@ -242,8 +244,11 @@ constexpr int RP = 280;
 // Launch shape: one WAVE per workgroup (64 threads, blockIdx = tile*4 + wave): the waves share
 // nothing, so giving each its own workgroup lets the dispatcher refill a finished wave's slot
 // at once and lifts the occupancy limit from 4 to 5 waves per SIMD (LDS: 8960 B per wave).
+#ifndef ALOHA_ROW_INV_WAVES
+#define ALOHA_ROW_INV_WAVES 1   // 5 would hold the inverse instantiations to 96 VGPRs (they settle at 106-110: 4 waves per SIMD) at the price of 28 B of scratch: measured 2 % slower
+#endif
 template <bool INV, bool UNIA, bool FIRST, bool LAST>
-__global__ __launch_bounds__(64) void ntt_row_kernel(const LimbJob *__restrict__ jobs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INV ? ALOHA_ROW_INV_WAVES : 1))) void ntt_row_kernel(const LimbJob *__restrict__ jobs,
                                                      const PrimeDev *__restrict__ primes,
                                                      const TileDesc *__restrict__ tiles) {
   __shared__ u64 sdata[1][4 * RP];
