@@ -239,7 +239,17 @@ __global__ __launch_bounds__(256) void ntt_col_small_kernel(const LimbJob *__res
 // B mapping: lane (lw = lane & 3, kh = lane >> 2) holds points 16*kh + j
 // LDS slot of point p of wave-line lw: lw*RP + p + (p >> 4); RP = 280 (== 24 mod 32) makes the
 // B-mapping 64-bit reads conflict-free.
+// ALOHA_ROW_BMAP=1 (lw = lane >> 4, kh = lane & 15, RP = 272) makes BOTH mappings conflict-free
+// (SQ_LDS_BANK_CONFLICT 33.5 M -> 0 cycles per launch, LDS active cycles -33 %) and was measured 0.8 %
+// SLOWER end to end (2.50 vs 2.52 M NTT/s): the LDS is 24 % busy in this kernel, not a limiter.
+#ifndef ALOHA_ROW_BMAP
+#define ALOHA_ROW_BMAP 0
+#endif
+#if ALOHA_ROW_BMAP
+constexpr int RP = 272;            // == 16 (mod 32)
+#else
 constexpr int RP = 280;
+#endif
 
 // Launch shape: one WAVE per workgroup (64 threads, blockIdx = tile*4 + wave): the waves share
 // nothing, so giving each its own workgroup lets the dispatcher refill a finished wave's slot
@@ -264,7 +274,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INV ? ALOHA_
   u64 *lds = sdata[0];
 
   const uint32_t plA = lane & 15, lwA = lane >> 4;
+#if ALOHA_ROW_BMAP
+  const uint32_t lwB = lane >> 4, khB = lane & 15;
+#else
   const uint32_t lwB = lane & 3, khB = lane >> 2;
+#endif
   const uint32_t lineA = 4 * w + lwA, lineB = 4 * w + lwB;
   const uint32_t rowA = chunk * rpt + (lineA >> pb_log), rowB = chunk * rpt + (lineB >> pb_log);
   const uint32_t rowU = chunk * rpt + ((4 * w) >> pb_log);               // wave-uniform when pb_log >= 2
