@@ -229,6 +229,54 @@ __global__ __launch_bounds__(256) void dot_batch_kernel(const DotArgs *__restric
   }
 }
 
+// exact-quotient Shoup product with a wave-uniform constant, on the pinned multiplier forms: [0, 2q) for ANY a
+__device__ __forceinline__ u64 shoup_2q_u(u64 a, u64 s, u64 sp, u64 nq) {
+  return mullo2_acc<true>(a, s, shoup_qhat_exact<true>(a, sp), nq);
+}
+
+__global__ __launch_bounds__(256) void sum_group_kernel(const SumGroup *__restrict__ groups, const SumJob *__restrict__ jobs,
+                                                        uint32_t n2) {
+  const SumGroup *g = &groups[blockIdx.y];                   // wave-uniform: pointers and scalars come through scalar loads
+  const int T = g->nterms;
+  const uint32_t first = g->first, count = g->count;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+    u64x2 v[kSumTerms];
+#pragma unroll
+    for (int t = 0; t < kSumTerms; t++)
+      if (t < T) v[t] = reinterpret_cast<const u64x2 *>(g->a[t])[i];
+    for (uint32_t j = 0; j < count; j++) {
+      const SumJob *jb = &jobs[first + j];
+      const u64 q = jb->m.q, nq = jb->m.nq;
+      u64 ax = 0, ay = 0;
+      if (T <= 4) {                                           // <= 4 products < 4q each (approximate quotient, 3 instructions fewer)
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+          if (t < T) {
+            const u64 sc = jb->s[t], sp = jb->sp[t];
+            ax += mul_shoup_4q<true>(v[t].x, sc, sp, nq);
+            ay += mul_shoup_4q<true>(v[t].y, sc, sp, nq);
+          }
+      } else {                                                // <= 8 products < 2q each (exact quotient): < 16q < 2^64 either way
+#pragma unroll
+        for (int t = 0; t < kSumTerms; t++)
+          if (t < T) {
+            const u64 sc = jb->s[t], sp = jb->sp[t];
+            ax += shoup_2q_u(v[t].x, sc, sp, nq);
+            ay += shoup_2q_u(v[t].y, sc, sp, nq);
+          }
+      }
+      const u32 kc = (u32)jb->m.kc;
+      const u64 c = jb->cst;
+      u64x2 r;
+      r.x = addmod(canon_any(ax, q, nq, kc), c, q);
+      r.y = addmod(canon_any(ay, q, nq, kc), c, q);
+      u64x2 *dst = reinterpret_cast<u64x2 *>(jb->d) + i;
+      __builtin_nontemporal_store(r.x, &dst->x);
+      __builtin_nontemporal_store(r.y, &dst->y);
+    }
+  }
+}
+
 inline uint32_t grid_for(uint32_t work_items) {
   uint32_t g = (work_items + 255) / 256;
   return g > 2048 ? 2048 : (g ? g : 1);
@@ -294,6 +342,15 @@ hipError_t dot_batch(hipStream_t st, const DotArgs *d_jobs, uint32_t njobs, uint
   uint32_t gx = grid_for(n2);
   while (gx > 16 && (uint64_t)gx * njobs > 8192) gx /= 2;    // plenty of workgroups already: longer grid-stride loops instead
   hipLaunchKernelGGL(dot_batch_kernel, dim3(gx, njobs), dim3(256), 0, st, d_jobs, n2);
+  return hipGetLastError();
+}
+
+hipError_t sum_groups(hipStream_t st, const SumGroup *d_groups, uint32_t ngroups, const SumJob *d_jobs, uint32_t n) {
+  if (!ngroups) return hipSuccess;
+  const uint32_t n2 = n / 2;
+  uint32_t gx = (n2 + 255) / 256;                            // one element pair per thread: the loop over outputs is the work
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(sum_group_kernel, dim3(gx ? gx : 1, ngroups), dim3(256), 0, st, d_groups, d_jobs, n2);
   return hipGetLastError();
 }
 

@@ -71,6 +71,25 @@ hipError_t dot(hipStream_t st, const DotArgs &args, uint32_t n);
 // phase together fill the chip, where a single one occupies 128 workgroups
 hipError_t dot_batch(hipStream_t st, const DotArgs *d_jobs, uint32_t njobs, uint32_t n);
 
+// Sums of SCALED operands that share their operands (a basis conversion: for one digit, the same alpha
+// coefficient-form limbs times a different scalar row under every target modulus).  As separate dot jobs
+// each output re-reads the operands; a group reads them once per element and loops over its outputs:
+//   d_j[i] = sum_t a_t[i] * s_jt  (+ cst_j)   mod q_j      for every job j of the group.
+constexpr int kSumTerms = 8;
+struct SumGroup {
+  const u64 *a[kSumTerms];
+  int nterms;              // 1..kSumTerms
+  uint32_t first, count;   // jobs [first, first + count) of the job array
+  uint32_t pad;
+};
+struct SumJob {
+  u64 s[kSumTerms], sp[kSumTerms];   // scalars (< q) and their Shoup companions
+  u64 cst;                           // constant term (< q), 0 if none
+  u64 *d;
+  ModCtx m;
+};
+hipError_t sum_groups(hipStream_t st, const SumGroup *d_groups, uint32_t ngroups, const SumJob *d_jobs, uint32_t n);
+
 // ---- transforms --------------------------------------------------------------------------
 // Device-resident twiddle set of one (q, N); tables hold (w, floor(w*2^64/q)) pairs.
 struct TwiddleDev {

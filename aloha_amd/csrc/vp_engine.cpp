@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <array>
 #include <map>
 #include <memory>
 #include <string>
@@ -586,12 +587,79 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       }
     }
     else if (pend_kind == PK_DOT && !dot_batch.empty()) {
-      const void *dj = nullptr;
-      s = device_blob(vp, dot_batch.data(), dot_batch.size() * sizeof(dot_batch[0]), &dj);
-      if (!s) {
-        hipError_t e = aloha::k::dot_batch(st, (const aloha::k::DotArgs *)dj, (uint32_t)dot_batch.size(), 1u << batch_logn);
-        vp->stats.kernel_launches++;
-        if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "dot_batch: %s", hipGetErrorString(e));
+      // Jobs that are sums of scaled operands over the SAME operands (a basis conversion: one digit under every
+      // target modulus) leave as groups -- the operands are read once per element instead of once per output.
+      std::vector<aloha::k::SumGroup> groups;
+      std::vector<aloha::k::SumJob> sjobs;
+      std::vector<aloha::k::DotArgs> rest;
+      if (fuse && dot_batch.size() >= 4) {
+        std::map<std::array<const u64 *, aloha::k::kSumTerms>, std::vector<size_t>> by_ops;
+        std::vector<char> grouped(dot_batch.size(), 0);
+        for (size_t i = 0; i < dot_batch.size(); i++) {
+          const auto &g = dot_batch[i];
+          std::array<const u64 *, aloha::k::kSumTerms> key{};
+          int nv = 0;
+          bool ok = !g.init;
+          for (int t = 0; ok && t < g.nterms; t++) {
+            if (g.b[t]) ok = false;                                 // a vector x vector term
+            else if (g.a[t]) { if (nv == aloha::k::kSumTerms) ok = false; else key[nv++] = g.a[t]; }
+          }
+          if (ok && nv) by_ops[key].push_back(i);
+        }
+        for (const auto &kv : by_ops) {
+          if (kv.second.size() < 4) continue;
+          // a group's outputs are a serial loop inside one thread: at most kPerGroup of them per group, so that
+          // there are enough workgroups in flight (the operands are then re-read once per sub-group, from L2)
+          constexpr size_t kPerGroup = 4;
+          for (size_t j0 = 0; j0 < kv.second.size(); j0 += kPerGroup) {
+            aloha::k::SumGroup sg{};
+            int nv = 0;
+            while (nv < aloha::k::kSumTerms && kv.first[nv]) { sg.a[nv] = kv.first[nv]; nv++; }
+            sg.nterms = nv; sg.first = (uint32_t)sjobs.size();
+            sg.count = (uint32_t)std::min(kPerGroup, kv.second.size() - j0);
+            for (size_t jj = j0; jj < j0 + sg.count; jj++) {
+              const size_t i = kv.second[jj];
+              const auto &g = dot_batch[i];
+              aloha::k::SumJob sj{};
+              int v = 0;
+              for (int t = 0; t < g.nterms; t++) {
+                if (g.a[t]) { sj.s[v] = g.s[t]; sj.sp[v] = g.sp[t]; v++; }
+                else { sj.cst += g.s[t]; if (sj.cst >= g.m.q) sj.cst -= g.m.q; }
+              }
+              sj.d = g.d; sj.m = g.m;
+              sjobs.push_back(sj);
+              grouped[i] = 1;
+            }
+            groups.push_back(sg);
+          }
+        }
+        if (!groups.empty())
+          for (size_t i = 0; i < dot_batch.size(); i++) if (!grouped[i]) rest.push_back(dot_batch[i]);
+      }
+      const std::vector<aloha::k::DotArgs> &plain = groups.empty() ? dot_batch : rest;
+      if (!groups.empty()) {
+        // one blob: groups first, then jobs (device_blob hands out one region per call)
+        std::vector<unsigned char> blob(groups.size() * sizeof(groups[0]) + sjobs.size() * sizeof(sjobs[0]));
+        memcpy(blob.data(), groups.data(), groups.size() * sizeof(groups[0]));
+        memcpy(blob.data() + groups.size() * sizeof(groups[0]), sjobs.data(), sjobs.size() * sizeof(sjobs[0]));
+        const void *dg = nullptr;
+        s = device_blob(vp, blob.data(), blob.size(), &dg);
+        if (!s) {
+          hipError_t e = aloha::k::sum_groups(st, (const aloha::k::SumGroup *)dg, (uint32_t)groups.size(),
+                                              (const aloha::k::SumJob *)((const unsigned char *)dg + groups.size() * sizeof(groups[0])),
+                                              1u << batch_logn);
+          vp->stats.kernel_launches++;
+          if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "sum_groups: %s", hipGetErrorString(e));
+        }
+      }
+      if (!s && !plain.empty()) {
+        const void *dj = nullptr;
+        s = device_blob(vp, plain.data(), plain.size() * sizeof(plain[0]), &dj);
+        if (!s) {
+          hipError_t e = aloha::k::dot_batch(st, (const aloha::k::DotArgs *)dj, (uint32_t)plain.size(), 1u << batch_logn);
+          vp->stats.kernel_launches++;
+          if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "dot_batch: %s", hipGetErrorString(e));
+        }
       }
     }
     batch.clear(); aut_batch.clear(); ew_batch.clear(); dot_batch.clear(); pend_rw.clear();
