@@ -461,6 +461,57 @@ def _random_program(rng, n, primes, nslots, length):
     return "\n".join(lines + ["break"])
 
 
+@pytest.mark.parametrize("logn", [10, 13, 16])
+def test_grouped_basis_conversion_sums_match_oracle(engine, logn):
+    """Sums of scaled operands that SHARE their operands (the shape of a ModUp / mod-down basis conversion) leave the
+    sequencer as groups: T = 1..8 shared operands (both product forms of the kernel), 5-9 outputs per operand set under
+    different moduli, with and without constant terms, operands that are NOT canonical for the target modulus, and
+    jobs that do not qualify (a vector x vector term, a lone operand set) in the same deferred batch."""
+    n = 1 << logn
+    rows = n // 128
+    rng = np.random.default_rng(77 + logn)
+    primes = [oracle.nth_prime(max(logn, 13), i) for i in range(9)]
+    nops = 8
+    ops = np.stack([rng.integers(0, 1 << 60, n, dtype=np.uint64) for _ in range(nops)])      # any 60-bit words
+    ops[0, :4] = [0, (1 << 60) - 1, primes[0], primes[0] - 1]
+    lines = [f"vsetvl {64 * n:#x}"]
+    off = lambda slot: slot * 8 * n
+    out = nops
+    for T in range(1, 9):
+        for j in range(5 + T % 5):
+            q = primes[(j + T) % len(primes)]
+            lines.append(f"vsetq {q:#x}")
+            for t in range(T):
+                sc = int(rng.integers(0, q)) if (t + j) % 4 else (1 if t % 2 else q - 1)
+                lines += [f"vle v0, src0+{off(t):#x}", f"vfqmul.vs v{6 if t == 0 else 3}, v0, {sc:#x}"]
+                if t:
+                    lines.append("vfqadd.vv v6, v6, v3")
+            if j % 3 == 1:
+                lines.append(f"vfqsub.vs v6, v6, {int(rng.integers(0, q)):#x}")
+            if j % 3 == 2:
+                lines.append(f"vfqadd.vs v6, v6, {int(rng.integers(0, q)):#x}")
+            lines.append(f"vse v6, src0+{off(out):#x}")
+            out += 1
+    # the same batch also carries jobs that must stay ordinary dot products
+    lines += [f"vsetq {primes[0]:#x}", f"vle v0, src0+{off(0):#x}", f"vle v1, src0+{off(1):#x}", "vfqmul.vv v6, v0, v1",
+              f"vle v0, src0+{off(2):#x}", f"vfqmul.vs v3, v0, 0x5", "vfqadd.vv v6, v6, v3", f"vse v6, src0+{off(out):#x}"]
+    out += 1
+    lines += [f"vle v0, src0+{off(7):#x}", f"vfqmul.vs v6, v0, 0x7", f"vle v0, src0+{off(3):#x}", "vfqmul.vs v3, v0, 0x9",
+              "vfqadd.vv v6, v6, v3", f"vse v6, src0+{off(out):#x}"]
+    out += 1
+    words = isa.assemble("\n".join(lines + ["break"]))
+    assert len(words) <= isa.IRAM_DEPTH
+    o = oracle.OracleVP(spm_rows=out * rows, ksk_rows=1)
+    res = []
+    for vp in (engine, o):
+        vp.write(SPM, 0, np.zeros(out * n, np.uint64)); vp.write(SPM, 0, ops.reshape(-1))
+        vp.load_isram(0, np.zeros((isa.IRAM_DEPTH, 3), np.uint32)); vp.load_isram(0, words)
+        assert vp.run(0, src0=0) == 0
+        vp.sync()
+        res.append(vp.read(SPM, 0, out * n))
+    assert np.array_equal(res[0], res[1])
+
+
 @pytest.mark.parametrize("seed", range(32))
 def test_random_programs_fused_unfused_oracle(engine, seed):
     """Differential fuzz of the sequencer: fused engine == unfused engine == oracle on all memory."""
