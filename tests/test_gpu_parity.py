@@ -3,6 +3,8 @@ reference's golden vectors.  Bit-exact (integer path): every comparison is array
 
 Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -135,6 +137,60 @@ def test_ntt_worst_case_ranges(engine):
         engine.ntt_rows(SPM, 0, 0, logn, [q] * 4, inverse=True)
         back = engine.read(SPM, 0, 4 * n).reshape(4, n)
         assert np.array_equal(back, pats % np.uint64(q))
+
+
+def _is_prime(p):
+    if p % 2 == 0:
+        return p == 2
+    d, r = p - 1, 0
+    while d % 2 == 0:
+        d //= 2; r += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):       # deterministic below 3.3e24
+        x = pow(a, d, p)
+        if x in (1, p - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % p
+            if x == p - 1:
+                break
+        else:
+            return False
+    return True
+
+
+@pytest.mark.parametrize("logn", [12, 13, 16])
+def test_ntt_primes_across_the_60_bit_range(engine, logn):
+    """The lazy ranges are stated in units of q, so the margins differ between q just above 2^59 (memory words up
+    to 2^60 - 1 are almost 2q) and q just below 2^60 (16q almost 2^64): primes drawn from the bottom, the middle and
+    the top of (2^59, 2^60), adversarial and random words, forward, inverse and round trip against the oracle."""
+    n = 1 << logn
+    rng = np.random.default_rng(900 + logn)
+    two_n = 2 * n
+    primes = []
+    for base in ((1 << 59) + 1, 3 << 58, (1 << 60) - (1 << 41)):   # the search below moves up by < 2^30 from base + 2^40
+        r = (base + int(rng.integers(0, 1 << 40))) // two_n * two_n + 1
+        for _ in range(100000):
+            if _is_prime(r):
+                break
+            r += two_n
+        assert _is_prime(r) and (1 << 59) < r < (1 << 60)
+        primes.append(r)
+    primes.append(oracle.nth_prime(logn, 0))                        # and the largest one there is
+    for q in primes:
+        pats = np.stack([np.full(n, q - 1, np.uint64), np.full(n, (1 << 60) - 1, np.uint64),
+                         np.where(np.arange(n) % 2 == 0, q - 1, 0).astype(np.uint64),
+                         np.where(np.arange(n) < n // 2, q - 1, 1).astype(np.uint64),
+                         rng.integers(0, 1 << 60, n, dtype=np.uint64), rng.integers(0, q, n, dtype=np.uint64)])
+        k = len(pats)
+        canon = pats % np.uint64(q)
+        for inverse, ref in ((False, oracle.ntt), (True, oracle.intt)):
+            engine.write(SPM, 0, pats.reshape(-1))
+            engine.ntt_rows(SPM, 0, 0, logn, [q] * k, inverse=inverse)
+            got = engine.read(SPM, 0, k * n).reshape(k, n)
+            for i in range(k):
+                assert np.array_equal(got[i], ref(canon[i], q)), (hex(q), inverse, i)
+            engine.ntt_rows(SPM, 0, 0, logn, [q] * k, inverse=not inverse)
+            assert np.array_equal(engine.read(SPM, 0, k * n).reshape(k, n), canon), (hex(q), inverse, "round trip")
 
 
 @pytest.mark.parametrize("logn", [12, 13, 14])
@@ -512,7 +568,7 @@ def test_grouped_basis_conversion_sums_match_oracle(engine, logn):
     assert np.array_equal(res[0], res[1])
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ALOHA_FUZZ_SEEDS", "32"))))   # (a longer soak: ALOHA_FUZZ_SEEDS=400)
 def test_random_programs_fused_unfused_oracle(engine, seed):
     """Differential fuzz of the sequencer: fused engine == unfused engine == oracle on all memory."""
     rng = np.random.default_rng(1000 + seed)
