@@ -16,11 +16,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <algorithm>
 #include <array>
 #include <map>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -100,6 +102,21 @@ struct aloha_vp {
   std::map<unsigned, EncTab> enc_tables;
   void *d_enc_in = nullptr, *d_enc_work = nullptr;
   size_t enc_in_bytes = 0, enc_work_bytes = 0;
+  // Launch lists of whole program runs, replayed when the same program segment is run again with the same CSRs
+  // and the same architectural state on entry: the sequencer is a pure function of those (no data-dependent
+  // control flow in the ISA), so a repeated phase of a key-switch costs its kernel launches and nothing else.
+  struct RunPlan {
+    std::vector<uint32_t> inst;                      // the segment [pc, break]
+    std::vector<uint64_t> imm;
+    uint64_t csr[4] = {0, 0, 0, 0}, step = 0, vl_in = 0, q_in = 0, mu_in = 0, vl_out = 0, q_out = 0, mu_out = 0;
+    uint32_t pc = 0;
+    uint64_t epoch = 0, instructions = 0;
+    std::vector<std::function<hipError_t()>> ops;
+  };
+  std::unordered_multimap<uint64_t, RunPlan> run_cache;
+  RunPlan *rec = nullptr;                            // non-null while a run is being recorded
+  uint64_t epoch = 0;                                // bumped whenever a cached device object a plan may point to is freed
+  bool run_cache_on = true;
   aloha_vp_stats stats{};
   std::string err;
 };
@@ -124,6 +141,14 @@ aloha_status fail(aloha_vp *vp, aloha_status s, const char *fmt, ...) {
     if (e_ != hipSuccess)                                                                   \
       return fail(vp, ALOHA_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));     \
   } while (0)
+
+// Every enqueue of a program run goes through here: executed now, and kept for replay while a run is recorded.
+template <class F>
+inline hipError_t issue(aloha_vp *vp, F f) {
+  const hipError_t e = f();
+  if (e == hipSuccess && vp->rec) vp->rec->ops.emplace_back(std::move(f));
+  return e;
+}
 
 u64 *vreg(aloha_vp *vp, unsigned r) { return vp->d_vreg + ((size_t)r << vp->max_logn); }
 
@@ -251,24 +276,29 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
     HIPCK(vp, hipStreamSynchronize(vp->stream));    // pageable sources go out of scope
     if (vp->plans.size() >= kMaxPlans) {            // evict the oldest; its kernels have drained (sync above)
       vp->plans.erase(vp->plans.begin());
+      vp->epoch++;                                  // recorded runs may point to it
     }
     plan = np.get();
     vp->plans.push_back(std::move(np));
   }
-  uint64_t launches = 0;
-  hipError_t e = hipSuccess;
-  if (plan->chunks.empty()) {
-    e = aloha::k::ntt_radix2_batch(vp->stream, plan->d_jobs, vp->d_primes, count, logn, 0, logn, inverse, true, true, &launches);
-  } else {
-    for (const PlanChunk &pc : plan->chunks) {
-      e = aloha::k::ntt_tile_batch(vp->stream, plan->d_jobs, plan->d_jobs + count, vp->d_primes, pc.limb_begin,
-                                   pc.limb_count, logn, inverse, plan->d_tiles + pc.uni_off, pc.n_uni,
-                                   plan->d_tiles + pc.glb_off, pc.n_glb, &launches,
-                                   (vp->flags & ALOHA_FLAG_NTT_TWO_PASS) ? 0u : (vp->flags & ALOHA_FLAG_NTT_SINGLE_14) ? 14u : 13u);
-      if (e != hipSuccess) break;
+  const TransformPlan *pl = plan;
+  const hipError_t e = issue(vp, [vp, pl, count, logn, inverse]() -> hipError_t {
+    uint64_t launches = 0;
+    hipError_t e = hipSuccess;
+    if (pl->chunks.empty()) {
+      e = aloha::k::ntt_radix2_batch(vp->stream, pl->d_jobs, vp->d_primes, count, logn, 0, logn, inverse, true, true, &launches);
+    } else {
+      for (const PlanChunk &pc : pl->chunks) {
+        e = aloha::k::ntt_tile_batch(vp->stream, pl->d_jobs, pl->d_jobs + count, vp->d_primes, pc.limb_begin,
+                                     pc.limb_count, logn, inverse, pl->d_tiles + pc.uni_off, pc.n_uni,
+                                     pl->d_tiles + pc.glb_off, pc.n_glb, &launches,
+                                     (vp->flags & ALOHA_FLAG_NTT_TWO_PASS) ? 0u : (vp->flags & ALOHA_FLAG_NTT_SINGLE_14) ? 14u : 13u);
+        if (e != hipSuccess) break;
+      }
     }
-  }
-  vp->stats.kernel_launches += launches;
+    vp->stats.kernel_launches += launches;
+    return e;
+  });
   if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "transform launch failed: %s", hipGetErrorString(e));
   return ALOHA_OK;
 }
@@ -332,6 +362,7 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   vp->ksk_rows = cfg->ksk_rows;
   vp->max_logn = cfg->max_log_n;
   if (const char *e = getenv("ALOHA_NTT_CHUNK")) vp->chunk_limbs = (uint32_t)strtoul(e, nullptr, 10);
+  vp->run_cache_on = !getenv("ALOHA_NO_RUN_CACHE");          // (A/B switch: every run goes through the sequencer again)
   vp->inst.assign(ALOHA_IRAM_DEPTH, 0);
   vp->imm.assign(ALOHA_IRAM_DEPTH, 0);
   auto bail = [&](const char *what) {
@@ -519,6 +550,7 @@ aloha_status device_blob(aloha_vp *vp, const void *host, size_t bytes, const voi
   if (vp->blobs.size() >= 512) {                             // everything queued has drained (sync above)
     (void)hipFree(vp->blobs.front().second);
     vp->blobs.erase(vp->blobs.begin());
+    vp->epoch++;                                             // recorded runs may point to it
   }
   vp->blobs.emplace_back(std::vector<uint8_t>((const uint8_t *)host, (const uint8_t *)host + bytes), d);
   *dev = d;
@@ -533,6 +565,56 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   const uint64_t csr[4] = {src0_row, src1_row, rslt_row, ksk_row};
   hipStream_t st = vp->stream;
   const bool fuse = !(vp->flags & ALOHA_FLAG_NO_FUSION);
+  // ---- replay of a recorded run (see aloha_vp::RunPlan) ---------------------------------------------
+  struct RecGuard { aloha_vp *v; ~RecGuard() { v->rec = nullptr; } } rec_guard{vp};
+  vp->rec = nullptr;
+  aloha_vp::RunPlan fresh;
+  uint64_t run_hash = 0;
+  const uint64_t instructions0 = vp->stats.instructions;
+  if (fuse && vp->run_cache_on && pc < ALOHA_IRAM_DEPTH) {
+    uint32_t end = pc;
+    while (end < ALOHA_IRAM_DEPTH && ((vp->inst[end] >> 26) & 0x3f) != 0x10) end++;      // break  expander.v:141-151
+    if (end < ALOHA_IRAM_DEPTH) {
+      const uint32_t len = end - pc + 1;
+      uint64_t h = 0xcbf29ce484222325ull;
+      auto mix = [&](uint64_t x) { h = (h ^ x) * 0x100000001b3ull; };
+      for (uint32_t i = pc; i <= end; i++) { mix(vp->inst[i]); mix(vp->imm[i]); }
+      for (int i = 0; i < 4; i++) mix(csr[i]);
+      mix(step); mix(vp->vl_bits); mix(vp->q); mix(vp->mu); mix(pc);
+      run_hash = h;
+      auto range = vp->run_cache.equal_range(h);
+      for (auto it = range.first; it != range.second; ++it) {
+        const aloha_vp::RunPlan &pl = it->second;
+        if (pl.epoch != vp->epoch || pl.pc != pc || pl.inst.size() != len || pl.step != step || pl.vl_in != vp->vl_bits ||
+            pl.q_in != vp->q || pl.mu_in != vp->mu || memcmp(pl.csr, csr, sizeof csr) != 0 ||
+            memcmp(pl.inst.data(), &vp->inst[pc], len * sizeof(uint32_t)) != 0 ||
+            memcmp(pl.imm.data(), &vp->imm[pc], len * sizeof(uint64_t)) != 0)
+          continue;
+        for (const auto &op : pl.ops) {
+          const hipError_t e = op();
+          if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "replayed launch failed: %s", hipGetErrorString(e));
+        }
+        vp->vl_bits = pl.vl_out; vp->q = pl.q_out; vp->mu = pl.mu_out;
+        vp->stats.instructions += pl.instructions;
+        return ALOHA_OK;
+      }
+      fresh.inst.assign(vp->inst.begin() + pc, vp->inst.begin() + end + 1);
+      fresh.imm.assign(vp->imm.begin() + pc, vp->imm.begin() + end + 1);
+      memcpy(fresh.csr, csr, sizeof csr);
+      fresh.step = step; fresh.vl_in = vp->vl_bits; fresh.q_in = vp->q; fresh.mu_in = vp->mu; fresh.pc = pc;
+      vp->rec = &fresh;
+    }
+  }
+  auto finish_recording = [&]() {
+    if (!vp->rec) return;
+    vp->rec = nullptr;
+    fresh.epoch = vp->epoch;
+    fresh.vl_out = vp->vl_bits; fresh.q_out = vp->q; fresh.mu_out = vp->mu;
+    fresh.instructions = vp->stats.instructions - instructions0;
+    if (vp->run_cache.size() >= 1024) { vp->run_cache.clear(); }
+    vp->run_cache.emplace(run_hash, std::move(fresh));
+  };
+  const uint64_t epoch0 = vp->epoch;
   const u64 *alias[ALOHA_NVREG] = {nullptr};                // non-null: the register's value is memory at this address
   // Pending batch: deferred memory-to-memory jobs of ONE kind, launched together by flush().
   enum { PK_NONE, PK_NTT, PK_AUT, PK_EW, PK_DOT } pend_kind = PK_NONE;
@@ -573,16 +655,23 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       if (!s) {
         bool two_pass = !getenv("ALOHA_AUT_GATHER");                    // (the variable is an A/B timing switch)
         for (const auto &j : aut_batch) two_pass = two_pass && !j.roll;
-        hipError_t e = aloha::k::aut_batch(st, (const aloha::k::AutJob *)dj, (uint32_t)aut_batch.size(), batch_logn, two_pass);
-        vp->stats.kernel_launches += (two_pass && batch_logn >= 12) ? 2 : 1;
+        const uint32_t nj = (uint32_t)aut_batch.size();
+        const unsigned bl = batch_logn;
+        hipError_t e = issue(vp, [=]() -> hipError_t {
+          vp->stats.kernel_launches += (two_pass && bl >= 12) ? 2 : 1;
+          return aloha::k::aut_batch(st, (const aloha::k::AutJob *)dj, nj, bl, two_pass);
+        });
         if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "aut_batch: %s", hipGetErrorString(e));
       }
     } else if (pend_kind == PK_EW && !ew_batch.empty()) {
       const void *dj = nullptr;
       s = device_blob(vp, ew_batch.data(), ew_batch.size() * sizeof(ew_batch[0]), &dj);
       if (!s) {
-        hipError_t e = aloha::k::ew_batch(st, (const aloha::k::EwJob *)dj, (uint32_t)ew_batch.size(), 1u << batch_logn);
-        vp->stats.kernel_launches++;
+        const uint32_t nj = (uint32_t)ew_batch.size(), nn = 1u << batch_logn;
+        hipError_t e = issue(vp, [=]() -> hipError_t {
+          vp->stats.kernel_launches++;
+          return aloha::k::ew_batch(st, (const aloha::k::EwJob *)dj, nj, nn);
+        });
         if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "ew_batch: %s", hipGetErrorString(e));
       }
     }
@@ -645,10 +734,12 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         const void *dg = nullptr;
         s = device_blob(vp, blob.data(), blob.size(), &dg);
         if (!s) {
-          hipError_t e = aloha::k::sum_groups(st, (const aloha::k::SumGroup *)dg, (uint32_t)groups.size(),
-                                              (const aloha::k::SumJob *)((const unsigned char *)dg + groups.size() * sizeof(groups[0])),
-                                              1u << batch_logn);
-          vp->stats.kernel_launches++;
+          const uint32_t ng = (uint32_t)groups.size(), nn = 1u << batch_logn;
+          const aloha::k::SumJob *djobs = (const aloha::k::SumJob *)((const unsigned char *)dg + groups.size() * sizeof(groups[0]));
+          hipError_t e = issue(vp, [=]() -> hipError_t {
+            vp->stats.kernel_launches++;
+            return aloha::k::sum_groups(st, (const aloha::k::SumGroup *)dg, ng, djobs, nn);
+          });
           if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "sum_groups: %s", hipGetErrorString(e));
         }
       }
@@ -656,8 +747,11 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         const void *dj = nullptr;
         s = device_blob(vp, plain.data(), plain.size() * sizeof(plain[0]), &dj);
         if (!s) {
-          hipError_t e = aloha::k::dot_batch(st, (const aloha::k::DotArgs *)dj, (uint32_t)plain.size(), 1u << batch_logn);
-          vp->stats.kernel_launches++;
+          const uint32_t nj = (uint32_t)plain.size(), nn = 1u << batch_logn;
+          hipError_t e = issue(vp, [=]() -> hipError_t {
+            vp->stats.kernel_launches++;
+            return aloha::k::dot_batch(st, (const aloha::k::DotArgs *)dj, nj, nn);
+          });
           if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "dot_batch: %s", hipGetErrorString(e));
         }
       }
@@ -697,8 +791,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         g.sp[t] = (g.b[t] || !g.a[t]) ? 0 : aloha::nt::shoup(g.s[t], lazy_q[r]);
       }
       g.init = init; g.d = dst; g.m = modctx(lazy_q[r]);
-      HIPCK(vp, aloha::k::dot(st, g, n));
-      vp->stats.kernel_launches++;
+      HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::dot(st, g, n); }));
       init = dst;
     }
     lazy[r].clear();
@@ -718,7 +811,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       if (!dead_from(vp, next_pc, r)) {
         aloha_status s = flush();                            // the copy must see memory as of program order
         if (s) return s;
-        HIPCK(vp, hipMemcpyAsync(vreg(vp, r), alias[r], n * 8, hipMemcpyDeviceToDevice, st));
+        {
+          u64 *cd = vreg(vp, r); const u64 *cs = alias[r]; const size_t cb = n * 8;
+          HIPCK(vp, issue(vp, [=]() -> hipError_t { return hipMemcpyAsync(cd, cs, cb, hipMemcpyDeviceToDevice, st); }));
+        }
       }
       alias[r] = nullptr;
     }
@@ -773,7 +869,11 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     }
 
     switch (funct6) {
-      case 0x10: return flush();                                   // break   expander.v:141-151
+      case 0x10: {                                                 // break   expander.v:141-151
+        const aloha_status sb = flush();
+        if (!sb && vp->epoch == epoch0) finish_recording();      // (an eviction during the run may have freed what an earlier op points to)
+        return sb;
+      }
       case 0x00: break;                                            // nop
       case 0x04: {                                                 // vsetvl  :156-159
         unsigned l;
@@ -789,7 +889,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
             if (alias[r]) {
               unsigned lo = 0;
               if (vl_logn(vp->vl_bits, vp->max_logn, &lo) == ALOHA_OK)
-                HIPCK(vp, hipMemcpyAsync(vreg(vp, r), alias[r], (size_t)8 << lo, hipMemcpyDeviceToDevice, st));
+              {
+                u64 *cd = vreg(vp, r); const u64 *cs = alias[r]; const size_t cb = (size_t)8 << lo;
+                HIPCK(vp, issue(vp, [=]() -> hipError_t { return hipMemcpyAsync(cd, cs, cb, hipMemcpyDeviceToDevice, st); }));
+              }
               alias[r] = nullptr;
             }
         }
@@ -870,8 +973,11 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           break;
         }
         ALOHA_RUN_CK(flush());
-        HIPCK(vp, aloha::k::ew(st, op, dst, a, b, s, aloha::nt::shoup(s, q), modctx(q), n));
-        vp->stats.kernel_launches++;
+        {
+          const u64 ssp = aloha::nt::shoup(s, q);
+          const aloha::k::ModCtx mc = modctx(q);
+          HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::ew(st, op, dst, a, b, s, ssp, mc, n); }));
+        }
         alias[vd] = nullptr;
         break;
       }
@@ -912,14 +1018,16 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           uint64_t kinv = 1;                                       // k^-1 mod N by Newton iteration (k odd)
           for (int it = 0; it < 5; it++) kinv = kinv * (2 - k * kinv);
           kinv &= (n - 1);
-          HIPCK(vp, aloha::k::vaut(st, out, in, logn, q, k, kinv));
+          HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::vaut(st, out, in, logn, q, k, kinv); }));
         } else if (funct6 == 0x1d) {
-          HIPCK(vp, aloha::k::vautn(st, out, in, logn, k));
+          HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::vautn(st, out, in, logn, k); }));
         } else {
-          HIPCK(vp, aloha::k::vroli(st, out, in, logn, k));
+          HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::vroli(st, out, in, logn, k); }));
         }
-        vp->stats.kernel_launches++;
-        if (inplace) HIPCK(vp, hipMemcpyAsync(dst, out, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        if (inplace) {
+          const size_t cb = (size_t)n * 8;
+          HIPCK(vp, issue(vp, [=]() -> hipError_t { return hipMemcpyAsync(dst, out, cb, hipMemcpyDeviceToDevice, st); }));
+        }
         alias[vd] = nullptr;
         break;
       }
@@ -961,7 +1069,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         if (!p) ALOHA_RUN_FAIL(ALOHA_ERR_ADDR, "pc %u: vle imm %#llx out of range", pc, (u64)imm);
         lazy[vd].clear();
         if (fuse) { alias[vd] = p; break; }                        // zero copy: alias until either side is overwritten
-        HIPCK(vp, hipMemcpyAsync(vreg(vp, vd), p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        {
+          u64 *cd = vreg(vp, vd); const size_t cb = (size_t)n * 8;
+          HIPCK(vp, issue(vp, [=]() -> hipError_t { return hipMemcpyAsync(cd, p, cb, hipMemcpyDeviceToDevice, st); }));
+        }
         break;
       }
       case 0x07: {                                                 // vse (source register = vs1)  :502-523,:687-692
@@ -1026,11 +1137,17 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         const u64 *src = rd(vs1);
         if (src == p) break;                                       // storing an alias back onto itself
         if (overlap(src, p, n)) {                                  // shifted self-overlap: go through the register
-          HIPCK(vp, hipMemcpyAsync(vp->d_scratch, src, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+          {
+            u64 *cd = vp->d_scratch; const u64 *cs = src; const size_t cb = (size_t)n * 8;
+            HIPCK(vp, issue(vp, [=]() -> hipError_t { return hipMemcpyAsync(cd, cs, cb, hipMemcpyDeviceToDevice, st); }));
+          }
           src = vp->d_scratch;
         }
         ALOHA_RUN_CK(before_mem_write(p, n, pc + 1));
-        HIPCK(vp, hipMemcpyAsync(p, src, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        {
+          const size_t cb = (size_t)n * 8;
+          HIPCK(vp, issue(vp, [=]() -> hipError_t { return hipMemcpyAsync(p, src, cb, hipMemcpyDeviceToDevice, st); }));
+        }
         break;
       }
       default:                                                     // RTL: silent no-op bundle (:524-532)

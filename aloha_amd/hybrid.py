@@ -192,8 +192,8 @@ def _scalar_sum(srcs: Sequence[int], scalars: Sequence[int], dst_off: int, minus
     return out + [f"vse v6, abs+{dst_off:#x}"]
 
 
-def blocks_phase1(lo: HybridLayout, mode: str) -> List[List[str]]:
-    b, o, B = [], lo.off, range(lo.B)
+def blocks_phase1(lo: HybridLayout, mode: str, bs=None) -> List[List[str]]:
+    b, o, B = [], lo.off, (range(lo.B) if bs is None else bs)
     own = list(enumerate(lo.owned_ct))
     if mode == "rotate":
         for i, j in own:                                        # NTT-domain automorphism of both components
@@ -232,8 +232,8 @@ def blocks_phase1(lo: HybridLayout, mode: str) -> List[List[str]]:
     return b
 
 
-def blocks_modup(lo: HybridLayout) -> List[List[str]]:
-    b, o, B = [], lo.off, range(lo.B)
+def blocks_modup(lo: HybridLayout, bs=None) -> List[List[str]]:
+    b, o, B = [], lo.off, (range(lo.B) if bs is None else bs)
     for jl, j in enumerate(lo.owned_all):                       # basis extension sums
         m = lo.mods_all[j]
         for d in range(lo.dnum):
@@ -256,28 +256,32 @@ def blocks_modup(lo: HybridLayout) -> List[List[str]]:
     return b
 
 
-def blocks_inner(lo: HybridLayout, hoisted: bool = False) -> List[List[str]]:
+def blocks_inner(lo: HybridLayout, hoisted: bool = False, regions=None) -> List[List[str]]:
+    """``regions`` (hoisted rotations in one pass): slot b is rotation b of the ONE decomposed ciphertext in slot 0,
+    with its key in key region ``regions[b]``."""
     b, o = [], lo.off
     x_of = (lambda i, bi: lo.s_in(1, i, bi)) if hoisted else lo.s_x
     for jl, j in enumerate(lo.owned_all):
-        for bi in range(lo.B):
+        for bi in (range(lo.B) if regions is None else range(len(regions))):
             blk = _setq(lo.mods_all[j])
+            sb = bi if regions is None else 0                 # operand slot
+            kb = 0 if regions is None else regions[bi] * lo.ksk_limbs
             for c in range(2):
                 acc = 6 + 2 * c
                 for d in range(lo.dnum):
-                    src = o(x_of(lo.owned_ct.index(j), bi)) if j in lo.digit(d) else o(lo.s_sd(jl, d, bi))
-                    blk += [f"vle v0, abs+{src:#x}", f"vle v1, ksk+{((jl * lo.dnum + d) * 2 + c) * 8 * lo.n:#x}"]
+                    src = o(x_of(lo.owned_ct.index(j), sb)) if j in lo.digit(d) else o(lo.s_sd(jl, d, sb))
+                    blk += [f"vle v0, abs+{src:#x}", f"vle v1, ksk+{(kb + (jl * lo.dnum + d) * 2 + c) * 8 * lo.n:#x}"]
                     blk += [f"vfqmul.vv v{acc}, v0, v1"] if d == 0 else ["vfqmul.vv v3, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v3"]
                 blk.append(f"vse v{acc}, abs+{o(lo.s_acc(jl, c, bi)):#x}")
             b.append(blk)
     return b
 
 
-def blocks_moddown_terms(lo: HybridLayout) -> List[List[str]]:
+def blocks_moddown_terms(lo: HybridLayout, bs=None) -> List[List[str]]:
     """Two loops, each one batched launch: the special primes' accumulators to coefficient form (in place,
     they are not needed again), then W = (x + floor(P/2)) * (P/p_k)^-1 = x*c + floor(P/2)*c as a one-term sum
     with a constant."""
-    b, o, B = [], lo.off, range(lo.B)
+    b, o, B = [], lo.off, (range(lo.B) if bs is None else bs)
     acc = lambda k, c, bi: o(lo.s_acc(lo.owned_all.index(lo.L + k), c, bi))
     for k in lo.owned_sp:
         blk = _setq(lo.specials[k])
@@ -294,11 +298,12 @@ def blocks_moddown_terms(lo: HybridLayout) -> List[List[str]]:
     return b
 
 
-def blocks_finish(lo: HybridLayout, add_base1: bool, hoisted: bool = False) -> List[List[str]]:
+def blocks_finish(lo: HybridLayout, add_base1: bool, hoisted: bool = False, steps=None) -> List[List[str]]:
     """t = sum_k W_k * (P/p_k mod q_j) - floor(P/2)  (one fused sum), NTT, then
     out_c = acc_c * P^-1 + t_c * (-P^-1) + base_c  (one fused sum): two launches besides the transform.
-    ``hoisted``: base_0 is the unrotated c0 and the automorphism (vautn, CSR step) is applied to both results last."""
-    b, o, B = [], lo.off, range(lo.B)
+    ``hoisted``: base_0 is the unrotated c0 and the automorphism (vautn, CSR step) is applied to both results last.
+    ``steps``: slot b is rotation ``steps[b]`` of the ciphertext in slot 0 (the step rides in the instruction's immediate)."""
+    b, o, B = [], lo.off, (range(lo.B) if steps is None else range(len(steps)))
     own = list(enumerate(lo.owned_ct))
     for i, j in own:                                            # P-basis -> q_j, minus the rounding offset
         q = lo.moduli[j]
@@ -322,7 +327,7 @@ def blocks_finish(lo: HybridLayout, add_base1: bool, hoisted: bool = False) -> L
                 srcs = [o(lo.s_acc(jl, c, bi)), o(lo.s_s2(c, i, bi))]
                 scal = [pinv, q - pinv]
                 if c == 0:
-                    srcs.append(o(lo.s_in(0, i, bi) if hoisted else lo.s_rot(i, bi))); scal.append(1)
+                    srcs.append(o(lo.s_in(0, i, bi if steps is None else 0) if hoisted else lo.s_rot(i, bi))); scal.append(1)
                 elif add_base1:
                     srcs.append(o(lo.s_base1(i, bi))); scal.append(1)
                 b.append(_setq(q) + _scalar_sum(srcs, scal, o(lo.s_s1(c, i, bi) if hoisted else lo.s_out(c, i, bi))))
@@ -331,7 +336,8 @@ def blocks_finish(lo: HybridLayout, add_base1: bool, hoisted: bool = False) -> L
             blk = _setq(lo.moduli[j])
             for c in range(2):
                 for bi in B:
-                    blk += [f"vle v0, abs+{o(lo.s_s1(c, i, bi)):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{o(lo.s_out(c, i, bi)):#x}"]
+                    blk += [f"vle v0, abs+{o(lo.s_s1(c, i, bi)):#x}", f"vautn v2, v0, {0 if steps is None else int(steps[bi]):#x}",
+                            f"vse v2, abs+{o(lo.s_out(c, i, bi)):#x}"]
             b.append(blk)
     return b
 
@@ -511,6 +517,41 @@ class HybridKeySwitch:
         self._run("terms")
         self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.B * lo.n, lo.world, lo.rank)
         self._run("fin_h", step=k)
+
+    def hoist_one(self) -> None:
+        """``hoist()`` for the ciphertext in slot 0 only: the other ``batch`` slots then serve as ROTATION slots of
+        ``rotate_hoisted_many``."""
+        lo = self.lo
+        if "hoist1_1" not in self._p:
+            asm = lambda progs: [isa.assemble("\n".join(p)) for p in progs]
+            self._p["hoist1_1"] = asm(_pack(blocks_phase1(lo, "hoist", range(1)), lo.n)) if lo.Lr else []
+            self._p["modup_1"] = asm(_pack(blocks_modup(lo, range(1)), lo.n)) if lo.Mr else []
+            self._resident = False
+        self._run("hoist1_1")
+        self.ex.all_gather(self.vp, lo.row(lo.y), lo.Yr * lo.B * lo.n, lo.world, lo.rank)
+        self._run("modup_1")
+
+    def rotate_hoisted_many(self, steps: Sequence[int], regions: Optional[Sequence[int]] = None) -> None:
+        """R = len(steps) <= batch rotations of the ciphertext in slot 0 (after ``hoist_one()``) in ONE pass of the
+        phases: OUT slot b = rotation by ``steps[b]`` with the key of region ``regions[b]`` (default b).  Word for word
+        what R calls of ``rotate_hoisted`` produce, with the launches of a single call: every loop covers R times the
+        limbs (the latency-bound small transforms of the mod-down are shared by the R rotations)."""
+        lo = self.lo
+        steps = [int(k) for k in steps]
+        regions = list(range(len(steps))) if regions is None else [int(r) for r in regions]
+        assert 0 < len(steps) <= lo.B and len(regions) == len(steps)
+        key = ("many", tuple(steps), tuple(regions))
+        if key not in self._p:
+            asm = lambda progs: [isa.assemble("\n".join(p)) for p in progs]
+            R = range(len(steps))
+            self._p[key] = asm(_pack(blocks_inner(lo, True, regions), lo.n)) if lo.Mr else []
+            self._p[key + ("terms",)] = asm(_pack(blocks_moddown_terms(lo, R), lo.n)) if lo.owned_sp else []
+            self._p[key + ("fin",)] = asm(_pack(blocks_finish(lo, False, True, steps), lo.n)) if lo.Lr else []
+            self._resident = False
+        self._run(key)
+        self._run(key + ("terms",))
+        self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.B * lo.n, lo.world, lo.rank)
+        self._run(key + ("fin",))
 
     def rescale(self) -> None:
         """CT_IN (L limbs) -> OUT (limbs 0 .. L-2 valid): divide by the last ciphertext prime, rounding.

@@ -593,6 +593,16 @@ def test_random_programs_fused_unfused_oracle(engine, seed):
         assert res[0][0] == res[1][0] == res[2][0] == 0
         assert np.array_equal(res[0][1], res[2][1]), "fused engine vs oracle"
         assert np.array_equal(res[1][1], res[2][1]), "unfused engine vs oracle"
+        # the same program again on OTHER data: the fused engine now replays its recorded launch list
+        mem2 = np.stack([residues(rng, n, primes[0]) for _ in range(nslots)])
+        again = []
+        for vp in (engine, o):
+            vp.write(SPM, 0, np.zeros(total, np.uint64))
+            vp.write(SPM, 0, mem2.reshape(-1))
+            assert vp.run(0, src0=0, step=2 * seed + 1) == 0
+            vp.sync()
+            again.append(vp.read(SPM, 0, total))
+        assert np.array_equal(again[0], again[1]), "replayed run vs oracle"
     finally:
         plain.close()
 

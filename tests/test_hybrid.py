@@ -34,6 +34,8 @@ def _random_case(n, L, K, alpha, seed):
 
 
 def _run(vp, n, mods, specials, alpha, ct, key, op, k=0, **kw):
+    if op == "many":                                            # two rotation slots; read_out() then returns both results
+        kw = dict(kw, batch=2)
     hs = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha, **kw)
     hs.load_key(key); hs.load_ct(ct)
     if op == "multiply":
@@ -43,6 +45,11 @@ def _run(vp, n, mods, specials, alpha, ct, key, op, k=0, **kw):
     elif op == "hoisted":                                       # the same key bits serve as "the key of step k" and of step 3k
         hs.load_key_hoisted(key, k, 0); hs.load_key_hoisted(key, 3 * k % (2 * n), 1)
         hs.hoist(); hs.rotate_hoisted(k, 0); hs.rotate_hoisted(3 * k % (2 * n), 1)
+    elif op == "many":                                          # (needs batch >= 2: slot 1 = the second rotation)
+        hs.load_key_hoisted(key, k, 0); hs.load_key_hoisted(key, 3 * k % (2 * n), 1)
+        hs.hoist_one(); hs.rotate_hoisted_many([k, 3 * k % (2 * n)])
+        one = hs.read_out
+        hs.read_out = lambda: np.concatenate([one(0), one(1)])
     else:
         hs.rotate(k)
     return hs
@@ -138,6 +145,23 @@ def test_hoisted_rotations_decrypt_correctly(alpha, K):
     for k, out in zip(steps, outs):
         got, exp = toy.decrypt(out), toy.automorph(m, k)
         assert max(abs(a - b) for a, b in zip(got, exp)) < 1 << 22
+
+
+def test_hoisted_rotations_in_one_pass_equal_one_by_one():
+    """rotate_hoisted_many: the batch slots as rotation slots, steps in the instruction immediates, keys by region --
+    word for word the outputs of separate rotate_hoisted calls (also with the regions permuted)."""
+    n, L, K, alpha = 1024, 4, 2, 2
+    mods, specials, ct, key = _random_case(n, L, K, alpha, 5)
+    steps = [pow(3, r, 2 * n) for r in (1, 4, 6)]
+    keys = [np.roll(key, r, axis=1) for r in range(3)]
+    one = _hoisted(oracle.OracleVP(spm_rows=1 << 14, ksk_rows=1 << 15), n, mods, specials, alpha, ct, keys, steps)
+    hs = hybrid.HybridKeySwitch(oracle.OracleVP(spm_rows=1 << 15, ksk_rows=1 << 15), n, mods, specials, alpha, batch=4)
+    for i, (k, kk) in enumerate(zip(steps, keys)):
+        hs.load_key_hoisted(kk, k, i)
+    hs.load_ct(ct); hs.hoist_one(); hs.rotate_hoisted_many(steps)
+    assert all(np.array_equal(hs.read_out(b), one[b]) for b in range(3))
+    hs.rotate_hoisted_many(steps[::-1], [2, 1, 0])
+    assert all(np.array_equal(hs.read_out(b), one[2 - b]) for b in range(3))
 
 
 def test_rescale_divides_by_the_last_prime_under_decryption():
@@ -275,7 +299,7 @@ def _check_sharded(tmp_path, n, L, K, alpha, op, engine):
     assert seen == set(range(L))
 
 
-@pytest.mark.parametrize("op", ["rotate", "multiply", "rescale", "hoisted"])
+@pytest.mark.parametrize("op", ["rotate", "multiply", "rescale", "hoisted", "many"])
 def test_two_rank_hybrid_gloo(tmp_path, op):
     """L = 5, K = 2, alpha = 2 over two ranks (uneven shards, a special prime on each rank)."""
     _check_sharded(tmp_path, 1024, 5, 2, 2, op, "oracle")
@@ -298,7 +322,7 @@ def test_two_rank_batched_hybrid_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("op", ["rotate", "multiply", "rescale", "hoisted"])
+@pytest.mark.parametrize("op", ["rotate", "multiply", "rescale", "hoisted", "many"])
 def test_two_rank_hybrid_real_engines(tmp_path, op):
     _check_sharded(tmp_path, 4096, 5, 2, 2, op, "gpu")
 
@@ -318,8 +342,10 @@ def test_hybrid_on_gpu_matches_oracle_and_golden():
     for alpha in (2, 4):
         mods, specials, ct, key = _random_case(n, L, K, alpha, 40 + alpha)
         lo = hybrid.HybridLayout(n, mods, specials, alpha)
-        for op in ("rotate", "multiply", "rescale", "hoisted"):
+        for op in ("rotate", "multiply", "rescale", "hoisted", "many"):
             k = pow(3, 3, 2 * n)
+            if op == "many":
+                lo = hybrid.HybridLayout(n, mods, specials, alpha, batch=2)
             exp = _run(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=2 * lo.ksk_limbs * lo.rows), n, mods, specials, alpha,
                        ct, key, op, k).read_out()
             with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=2 * lo.ksk_limbs * lo.rows, max_log_n=16) as vp:

@@ -34,6 +34,7 @@ def main() -> int:
     ap.add_argument("--alpha", type=int, default=4)
     ap.add_argument("--op", choices=["rotate", "multiply", "hoisted"], default="multiply")
     ap.add_argument("--rotations", type=int, default=8, help="--op hoisted: rotation steps per decomposition (one key each)")
+    ap.add_argument("--many", action="store_true", help="--op hoisted: all rotations in one pass of the phases (rotate_hoisted_many)")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--verify", action="store_true")
@@ -42,6 +43,9 @@ def main() -> int:
     ap.add_argument("--stub-world", type=int, default=0,
                     help="time rank 0's share of a W-rank layout on this one GPU with the exchanges skipped (results meaningless)")
     args = ap.parse_args()
+    if args.many:
+        assert args.op == "hoisted" and args.batch == 1
+        args.batch = args.rotations                              # the batch slots are the rotation slots
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if args.stub_world:
         assert world == 1 and not args.verify
@@ -101,6 +105,10 @@ def main() -> int:
     steps = [pow(3, r + 1, 2 * n) for r in range(nkeys)]
 
     def hoisted():
+        if args.many:
+            ks.hoist_one()
+            ks.rotate_hoisted_many(steps)
+            return
         ks.hoist()
         for r, kr in enumerate(steps):
             ks.rotate_hoisted(kr, r)
@@ -142,7 +150,7 @@ def main() -> int:
             ok = bool(t[0] > 0.5)
     if rank == 0:
         print(json.dumps({"metric": f"{args.op} + key-switch at N=2^{logn}", "L": L, "alpha": args.alpha, "K": K, "n_gpus": world,
-                          "batch": args.batch, "exchange": "stubbed (rank 0's share only)" if args.stub_world else
+                          "batch": args.batch, "one_pass": bool(args.many), "exchange": "stubbed (rank 0's share only)" if args.stub_world else
                           ("host-synchronised" if ex.stream is None else "stream-ordered"),
                           "launches_per_op": (vp.stats()["kernel_launches"] - launches0) / args.reps,
                           "rotations_per_call": nkeys, "ms_per_rotation": elapsed / args.reps * 1e3 / nkeys,
