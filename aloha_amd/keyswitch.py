@@ -266,10 +266,16 @@ class Exchange:
     collectives are then enqueued stream-ordered -- RCCL waits for the phase's kernels through an event,
     the next phase's kernels wait for the collective -- and the host never blocks inside a key-switch;
     without it every exchange is bracketed by host synchronisation.  ``stub`` skips the communication
-    altogether (per-rank timing of a sharded layout on one GPU; results are then meaningless)."""
+    altogether (per-rank timing of a sharded layout on one GPU; results are then meaningless).
+
+    ``p2p``: MI355X nodes connect every GPU pair by its own xGMI link; a ring all-gather moves each chunk over
+    world-1 hops of ONE link each, while world-1 direct sends per rank (``batch_isend_irecv``: one RCCL group) put
+    1/(world-1) of the traffic on every link at once.  Off by default -- RCCL picks its own algorithm --
+    and identical in result (tests)."""
 
     def __init__(self, group=None, tensor_of: Optional[Callable] = None, always: bool = False, stream=None,
-                 stub: bool = False):
+                 stub: bool = False, p2p: bool = False):
+        self.p2p = p2p                # all-gather as world-1 concurrent sends + receives (one per xGMI link) instead of the collective
         self.group = group
         self.tensor_of = tensor_of
         self.always = always          # run the collectives even for world == 1 (single-rank NCCL smoke test)
@@ -284,16 +290,36 @@ class Exchange:
         import torch
         import torch.distributed as dist
         rows = chunk // LANES
+
+        def gather(buf):
+            mine = buf[rank * chunk:(rank + 1) * chunk]
+            if not self.p2p or world == 1:
+                dist.all_gather_into_tensor(buf, mine.clone(), group=self.group)
+                return
+            peer = (lambda r: dist.get_global_rank(self.group, r)) if self.group is not None else (lambda r: r)
+            ops = []
+            for d in range(1, world):                              # staggered so that no two ranks start on the same peer
+                to, frm = (rank + d) % world, (rank - d) % world
+                ops.append(dist.P2POp(dist.isend, mine, peer(to), group=self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[frm * chunk:(frm + 1) * chunk], peer(frm), group=self.group))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
         if self.tensor_of is not None and self.stream is not None:
             with torch.cuda.stream(self.stream):
-                buf = self.tensor_of(vp, row0, world * chunk)
-                dist.all_gather_into_tensor(buf, buf[rank * chunk:(rank + 1) * chunk].clone(), group=self.group)
+                gather(self.tensor_of(vp, row0, world * chunk))
             return
         vp.sync()
         if self.tensor_of is not None:
-            buf = self.tensor_of(vp, row0, world * chunk)
-            dist.all_gather_into_tensor(buf, buf[rank * chunk:(rank + 1) * chunk].clone(), group=self.group)
+            gather(self.tensor_of(vp, row0, world * chunk))
             torch.cuda.current_stream().synchronize()
+        elif self.p2p:
+            buf = torch.zeros(world * chunk, dtype=torch.int64)
+            buf[rank * chunk:(rank + 1) * chunk] = torch.from_numpy(vp.read(SPM, row0 + rank * rows, chunk).view(np.int64).copy())
+            gather(buf)
+            for r in range(world):
+                if r != rank:
+                    vp.write(SPM, row0 + r * rows, buf[r * chunk:(r + 1) * chunk].numpy().view(np.uint64))
         else:
             mine = torch.from_numpy(vp.read(SPM, row0 + rank * rows, chunk).view(np.int64).copy())
             parts = [torch.empty_like(mine) for _ in range(world)]

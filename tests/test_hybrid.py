@@ -258,7 +258,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, L, K, alpha, seed, k, op, out_dir, engine, batch=1):
+def _worker(rank, world, port, n, L, K, alpha, seed, k, op, out_dir, engine, batch=1, p2p=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -271,32 +271,39 @@ def _worker(rank, world, port, n, L, K, alpha, seed, k, op, out_dir, engine, bat
             vp = oracle.OracleVP(spm_rows=1 << 14, ksk_rows=1 << 14)
         if batch == 1:
             hs = _run(vp, n, mods, specials, alpha, ct, key, op, k, world=world, rank=rank,
-                      exchange=keyswitch.Exchange(group=None, tensor_of=None))
+                      exchange=keyswitch.Exchange(group=None, tensor_of=None, p2p=p2p))
             np.save(os.path.join(out_dir, f"out{rank}.npy"), hs.read_out())
         else:
             cts = [np.roll(ct, b, axis=1) for b in range(batch)]
             hs = _run_batch(vp, n, mods, specials, alpha, cts, key, op, k, world=world, rank=rank,
-                            exchange=keyswitch.Exchange(group=None, tensor_of=None))
+                            exchange=keyswitch.Exchange(group=None, tensor_of=None, p2p=p2p))
             np.save(os.path.join(out_dir, f"out{rank}.npy"), np.stack([hs.read_out(b) for b in range(batch)]))
         np.save(os.path.join(out_dir, f"own{rank}.npy"), np.array(hs.lo.owned_ct))
     finally:
         dist.destroy_process_group()
 
 
-def _check_sharded(tmp_path, n, L, K, alpha, op, engine):
+def _check_sharded(tmp_path, n, L, K, alpha, op, engine, world=2, p2p=False):
     seed, k = 17, pow(3, 5, 2 * n)
     mods, specials, ct, key = _random_case(n, L, K, alpha, seed)
     exp = _run(oracle.OracleVP(spm_rows=1 << 15, ksk_rows=1 << 15), n, mods, specials, alpha, ct, key, op, k).read_out()
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, n, L, K, alpha, seed, k, op, str(tmp_path), engine), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, n, L, K, alpha, seed, k, op, str(tmp_path), engine, 1, p2p), nprocs=world, join=True)
     seen = set()
-    for r in range(2):
+    for r in range(world):
         out = np.load(tmp_path / f"out{r}.npy")
         own = np.load(tmp_path / f"own{r}.npy")
         for i, j in enumerate(own):
             assert np.array_equal(out[:, i], exp[:, j]), f"rank {r} limb {j}"
             seen.add(int(j))
     assert seen == set(range(L))
+
+
+@pytest.mark.parametrize("op", ["rotate", "rescale"])
+def test_three_rank_hybrid_gloo_point_to_point_exchange(tmp_path, op):
+    """The all-gathers as world-1 direct sends and receives per rank (one per xGMI link on the node) instead of the
+    collective: three ranks, uneven shards, same words."""
+    _check_sharded(tmp_path, 1024, 5, 2, 2, op, "oracle", world=3, p2p=True)
 
 
 @pytest.mark.parametrize("op", ["rotate", "multiply", "rescale", "hoisted", "many"])

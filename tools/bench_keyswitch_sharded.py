@@ -39,6 +39,7 @@ def main() -> int:
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--verify", action="store_true")
     ap.add_argument("--batch", type=int, default=1, help="ciphertexts per call (hybrid only)")
+    ap.add_argument("--p2p", action="store_true", help="all-gathers as world-1 direct sends/receives per rank instead of the collective")
     ap.add_argument("--host-sync", action="store_true", help="bracket every exchange with host synchronisation (the old path)")
     ap.add_argument("--stub-world", type=int, default=0,
                     help="time rank 0's share of a W-rank layout on this one GPU with the exchanges skipped (results meaningless)")
@@ -68,7 +69,7 @@ def main() -> int:
     specials = [avp.nth_prime(logn, L + k) for k in range(K)]
     stream = torch.cuda.Stream()
     ex = keyswitch.Exchange(tensor_of=keyswitch.device_tensor if backend == "nccl" else None, always=False,
-                            stream=None if (args.host_sync or backend != "nccl") else stream, stub=bool(args.stub_world))
+                            stream=None if (args.host_sync or backend != "nccl") else stream, stub=bool(args.stub_world), p2p=args.p2p)
 
     def build(vp, w, r, exch):
         if args.alpha == 0:
