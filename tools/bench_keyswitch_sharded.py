@@ -105,15 +105,19 @@ def main() -> int:
     k = pow(3, 5, 2 * n)
     steps = [pow(3, r + 1, 2 * n) for r in range(nkeys)]
 
-    def hoisted():
-        if args.many:
+    def run_op(ks):
+        if args.op == "rotate":
+            ks.rotate(k)
+        elif args.op == "multiply":
+            ks.multiply()
+        elif args.many:
             ks.hoist_one()
             ks.rotate_hoisted_many(steps)
-            return
-        ks.hoist()
-        for r, kr in enumerate(steps):
-            ks.rotate_hoisted(kr, r)
-    op = (lambda: ks.rotate(k)) if args.op == "rotate" else (hoisted if args.op == "hoisted" else ks.multiply)
+        else:
+            ks.hoist()
+            for r, kr in enumerate(steps):
+                ks.rotate_hoisted(kr, r)
+    op = lambda: run_op(ks)
 
     def barrier():
         if dist.is_initialized() and world > 1:
@@ -141,10 +145,10 @@ def main() -> int:
         with avp.VP(spm_rows=lo1.spm_rows_needed, ksk_rows=nkeys * lo1.ksk_limbs * lo1.rows, max_log_n=logn, device=local) as vp1:
             ks1 = build(vp1, 1, 0, keyswitch.Exchange())
             load(ks1, lo1)
-            (ks1.rotate(k) if args.op == "rotate" else (ks1.multiply() if args.op == "multiply" else
-                                                         (ks1.hoist(), [ks1.rotate_hoisted(kr, r) for r, kr in enumerate(steps)])))
-            ref = ks1.read_out()
-        ok = all(np.array_equal(out[:, i], ref[:, j]) for i, j in enumerate(lo.owned_ct))
+            run_op(ks1)
+            refs = [ks1.read_out(b) for b in range(args.batch)] if args.alpha else [ks1.read_out()]
+        outs = [ks.read_out(b) for b in range(args.batch)] if args.alpha else [out]
+        ok = all(np.array_equal(o[:, i], r[:, j]) for o, r in zip(outs, refs) for i, j in enumerate(lo.owned_ct))
         if dist.is_initialized() and world > 1:
             t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
