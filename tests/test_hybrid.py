@@ -399,3 +399,32 @@ def test_baseline_configs_4_and_5_at_full_size_gpu_equals_oracle_machine(L, op):
     with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
         got = run(vp)
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.gpu
+def test_replayed_phases_on_new_data_and_new_steps():
+    """One handle, the same phase programs run again and again: the second and later calls replay recorded launch
+    lists.  New ciphertexts, another rotation step (a different CSR: a different list), a product in between --
+    every result equals the oracle machine's, which sequences every call from scratch."""
+    from aloha_amd import vp as avp
+    n, L, K, alpha = 1 << 13, 6, 2, 2
+    mods, specials, ct, key = _random_case(n, L, K, alpha, 71)
+    lo = hybrid.HybridLayout(n, mods, specials, alpha)
+    rng = np.random.default_rng(72)
+    cts = [ct] + [np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)]) for _ in range(3)]
+    steps = [pow(3, 2, 2 * n), pow(3, 2, 2 * n), pow(3, 7, 2 * n), pow(3, 2, 2 * n)]
+    with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=13) as vp:
+        g = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha)
+        o = hybrid.HybridKeySwitch(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows), n, mods, specials, alpha)
+        for hs in (g, o):
+            hs.load_key(key)
+        for i, (c, k) in enumerate(zip(cts, steps)):
+            for hs in (g, o):
+                hs.load_ct(c); hs.rotate(k)
+            assert np.array_equal(g.read_out(), o.read_out()), f"rotate #{i}"
+            for hs in (g, o):
+                hs.load_ct_b(cts[(i + 1) % len(cts)]); hs.multiply()
+            assert np.array_equal(g.read_out(), o.read_out()), f"multiply #{i}"
+            for hs in (g, o):
+                hs.rescale()
+            assert np.array_equal(g.read_out()[:, :L - 1], o.read_out()[:, :L - 1]), f"rescale #{i}"
