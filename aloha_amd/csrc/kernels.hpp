@@ -108,7 +108,12 @@ struct LimbJob {
   const u64 *src;
   u64 *dst;
   uint32_t prime;        // index into the PrimeDev table
-  uint32_t pad;
+  uint32_t scaled;       // inverse transforms only: 1 = multiply the result by the scalar folded into sc[] and add addc
+  // `vintt; vfqmul.vs c; [vfqadd.vs a]` as ONE transform: the last inverse stage already multiplies its sums by N^-1
+  // and its differences by w*N^-1 (ntt_device.hpp); with sc = {w*N^-1*c, its Shoup companion, N^-1*c, companion}
+  // the extra scalar costs nothing, and the constant is one modular add on the canonical result.
+  u64 sc[4];
+  u64 addc;
 };
 struct PrimeDev {
   ModCtx m;
@@ -141,12 +146,13 @@ hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *
                           const PrimeDev *d_primes, uint32_t begin, uint32_t count, unsigned logn,
                           bool inverse, const TileDesc *d_uni_tiles, uint32_t n_uni,
                           const TileDesc *d_glb_tiles, uint32_t n_glb, uint64_t *launches,
-                          unsigned single_max = 13);   // largest log2 N transformed by the single-pass kernels (0: never)
+                          unsigned single_max = 13,    // largest log2 N transformed by the single-pass kernels (0: never)
+                          bool scaled = false);       // inverse only: some job carries its own last-stage scalar (LimbJob::scaled)
 
 // Single-pass transforms for N = 2^12 .. 2^14 (the limb stays in one CU's LDS: one read + one write of
 // the limb, ntt_single.hip); d_jobs = the {src, dst} entries of the limbs to transform.
 hipError_t ntt_single_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
-                            unsigned logn, bool inverse, uint64_t *launches);
+                            unsigned logn, bool inverse, uint64_t *launches, bool scaled = false);
 
 // ---- CKKS encoder block (src/encoder), FP64: see encode_kernels.hip --------------------------------
 struct EncodeTables {      // per ring size N = 2^logn, n = N/2 slots; built by the host (vp_engine.cpp)

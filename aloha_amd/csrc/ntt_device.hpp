@@ -218,6 +218,24 @@ __device__ __forceinline__ void inv_radix16(u64 (&v)[16], const TW &tw, u64 q, u
 // [0, 4q) -> [0, q)
 __device__ __forceinline__ u64 canon_4q(u64 x, u64 q) { return csub_u(csub_u(x, q << 1), q); }
 
+// Constants of the last inverse stage: the prime's (w*N^-1, N^-1), or the job's own with its extra scalar folded in
+// (LimbJob::sc) plus a constant to add to the canonical result.  Wave-uniform (scalar loads).
+struct LastScale { tw_t w; u64 ni, nip, addc; };
+template <bool LAST>
+__device__ __forceinline__ LastScale last_scale(const LimbJob *jb, const PrimeDev *pr) {
+  LastScale s{tw_t{pr->tw.w1n_inv, pr->tw.w1n_inv_shoup}, pr->tw.n_inv, pr->tw.n_inv_shoup, 0};
+  if (LAST && jb->scaled) {
+    s.w = tw_t{jb->sc[0], jb->sc[1]};
+    s.ni = jb->sc[2]; s.nip = jb->sc[3]; s.addc = jb->addc;
+  }
+  return s;
+}
+template <bool SC>
+__device__ __forceinline__ u64 canon_last(u64 x, u64 q, u64 addc) {
+  const u64 r = canon_4q(x, q);
+  return (SC && addc) ? csub_u(r + addc, q) : r;             // (wave-uniform branch)
+}
+
 // twiddle accessors over one 256-entry block
 __device__ __forceinline__ tw_t load_tw(ctw_t p) {
   tw_t t;

@@ -64,7 +64,7 @@ struct TwPlain {
 #ifndef ALOHA_SINGLE_WAVES
 #define ALOHA_SINGLE_WAVES 4   // at least 4 waves per SIMD (<= 128 VGPRs): two workgroups per CU at N = 2^13
 #endif
-template <int LOGN, bool INV>
+template <int LOGN, bool INV, bool SC = false>
 __global__ __launch_bounds__((1 << LOGN) / 16) __attribute__((amdgpu_waves_per_eu(ALOHA_SINGLE_WAVES))) void ntt_single_kernel(const LimbJob *__restrict__ jobs,
                                                                        const PrimeDev *__restrict__ primes) {
   constexpr int N = 1 << LOGN, T = N / 16, E = LOGN - 12, NH = 16 >> E;     // NH = groups of 2^E registers in L3
@@ -164,29 +164,39 @@ __global__ __launch_bounds__((1 << LOGN) / 16) __attribute__((amdgpu_waves_per_e
     exchange(L2, L1, true);
     inv_radix16<false, INV_MID, false>(v, TwPlain{tab, 16, a1}, q, nq);                // stages 7..4
     exchange(L1, L0, false);
-    inv_radix16<true, INV_MID, true>(v, TwPlain{tab, 1, 0}, q, nq, tw_t{pr->tw.w1n_inv, pr->tw.w1n_inv_shoup},
-                                     pr->tw.n_inv, pr->tw.n_inv_shoup);               // stages 3..0, times N^-1
+    const LastScale ls = last_scale<SC>(&jobs[blockIdx.x], pr);
+    inv_radix16<true, INV_MID, true>(v, TwPlain{tab, 1, 0}, q, nq, ls.w, ls.ni, ls.nip);   // stages 3..0, times N^-1 (times the job's scalar)
 #pragma unroll
-    for (int r = 0; r < 16; r++) st_stream(dst + r * T + t, canon_4q(v[r], q));
+    for (int r = 0; r < 16; r++) st_stream(dst + r * T + t, canon_last<SC>(v[r], q, ls.addc));
   }
 }
 
-template <int LOGN, bool INV>
+template <int LOGN, bool INV, bool SC = false>
 hipError_t launch_single(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count) {
   constexpr int N = 1 << LOGN;
-  const void *fn = reinterpret_cast<const void *>(&ntt_single_kernel<LOGN, INV>);
+  const void *fn = reinterpret_cast<const void *>(&ntt_single_kernel<LOGN, INV, SC>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, N * 8);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((ntt_single_kernel<LOGN, INV>), dim3(count), dim3(N / 16), N * 8, st, d_jobs, d_primes);
+  hipLaunchKernelGGL((ntt_single_kernel<LOGN, INV, SC>), dim3(count), dim3(N / 16), N * 8, st, d_jobs, d_primes);
   return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t ntt_single_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count, unsigned logn,
-                            bool inverse, uint64_t *launches) {
+                            bool inverse, uint64_t *launches, bool scaled) {
   if (!count) return hipSuccess;
   hipError_t e;
+  if (inverse && scaled) {
+    switch (logn) {
+      case 12: e = launch_single<12, true, true>(st, d_jobs, d_primes, count); break;
+      case 13: e = launch_single<13, true, true>(st, d_jobs, d_primes, count); break;
+      case 14: e = launch_single<14, true, true>(st, d_jobs, d_primes, count); break;
+      default: return hipErrorInvalidValue;
+    }
+    if (launches) ++*launches;
+    return e;
+  }
   switch (logn * 2 + (inverse ? 1 : 0)) {
     case 24: e = launch_single<12, false>(st, d_jobs, d_primes, count); break;
     case 25: e = launch_single<12, true>(st, d_jobs, d_primes, count); break;

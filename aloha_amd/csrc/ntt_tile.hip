@@ -62,7 +62,7 @@ constexpr int TW_BLK = 256;        // twiddle entries per block
 // Both mappings touch memory in 128-byte row segments: forward loads in A and stores from B,
 // inverse loads in B and stores from A.  One LDS exchange and one barrier per tile.  The
 // stage 0..3 twiddles are the same for every thread (scalar loads -> SGPR operands).
-template <bool INV, bool FIRST, bool LAST>
+template <bool INV, bool FIRST, bool LAST, bool SC = false>     // SC: jobs may carry their own last-stage scalar (LimbJob::sc)
 __global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict__ jobs,
                                                       const PrimeDev *__restrict__ primes, uint32_t count) {
   __shared__ u64 sdata[LINES * PITCH];
@@ -126,11 +126,11 @@ __global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict_
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) v[kk] = sdata[col * PITCH + slow + 16 * kk];
-    inv_radix16<true, INV_MID, LAST>(v, TwStepA{blk}, q, nq, tw_t{pr->tw.w1n_inv, pr->tw.w1n_inv_shoup}, pr->tw.n_inv,
-                                     pr->tw.n_inv_shoup);
+    const LastScale ls = last_scale<LAST && SC>(&jobs[limb], pr);
+    inv_radix16<true, INV_MID, LAST>(v, TwStepA{blk}, q, nq, ls.w, ls.ni, ls.nip);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++)
-      st_stream(&(dst + ((size_t)(16 * kk) << 8))[offA], LAST ? canon_4q(v[kk], q) : v[kk]);
+      st_stream(&(dst + ((size_t)(16 * kk) << 8))[offA], LAST ? canon_last<SC>(v[kk], q, ls.addc) : v[kk]);
   }
 }
 
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict_
 //   row = ((kh * (16 >> E) + g) << E) + j,
 // for the last E stages.  Loads and stores are whole 2^(11-E)-byte row segments.  The reference's
 // own size, N = 8192, is E = 1.
-template <int E, bool INV, bool FIRST, bool LAST>
+template <int E, bool INV, bool FIRST, bool LAST, bool SC = false>
 __global__ __launch_bounds__(256) void ntt_col_small_kernel(const LimbJob *__restrict__ jobs,
                                                             const PrimeDev *__restrict__ primes) {
   constexpr int R = 16 << E, C = 256 >> E, GR = 16 >> E, PIT = R + 1;
@@ -221,11 +221,11 @@ __global__ __launch_bounds__(256) void ntt_col_small_kernel(const LimbJob *__res
       for (int k = 0; k < 16; k++) v[k] = ld_stream(&src[(size_t)rowA(k) << 8]);
     }
     // (with E = 0 and FIRST the registers hold memory operands, < 2q < INV_MID*q)
-    inv_radix16<true, INV_MID, LAST>(v, TwStepA{blk}, q, nq, tw_t{pr->tw.w1n_inv, pr->tw.w1n_inv_shoup}, pr->tw.n_inv,
-                                     pr->tw.n_inv_shoup);
+    const LastScale ls = last_scale<LAST && SC>(&jobs[limb], pr);
+    inv_radix16<true, INV_MID, LAST>(v, TwStepA{blk}, q, nq, ls.w, ls.ni, ls.nip);
 #pragma unroll
     for (int k = 0; k < 16; k++)
-      st_stream(&dst[(size_t)rowA(k) << 8], LAST ? canon_4q(v[k], q) : v[k]);
+      st_stream(&dst[(size_t)rowA(k) << 8], LAST ? canon_last<SC>(v[k], q, ls.addc) : v[k]);
   }
 }
 
@@ -435,22 +435,22 @@ void build_row_tiles(const LimbJob *h_jobs, uint32_t begin, uint32_t count, unsi
   }
 }
 
-template <bool INV, bool FIRST, bool LAST>
+template <bool INV, bool FIRST, bool LAST, bool SC = false>
 static void launch_cols(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
                         uint64_t *launches) {
   if (!count) return;
-  hipLaunchKernelGGL((ntt_col_kernel<INV, FIRST, LAST>), dim3(count * 16), dim3(256), 0, st, d_jobs, d_primes, count);
+  hipLaunchKernelGGL((ntt_col_kernel<INV, FIRST, LAST, SC>), dim3(count * 16), dim3(256), 0, st, d_jobs, d_primes, count);
   if (launches) ++*launches;
 }
 
-template <bool INV, bool FIRST, bool LAST>
+template <bool INV, bool FIRST, bool LAST, bool SC = false>
 static void launch_cols_small(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
                               unsigned e, uint64_t *launches) {
   if (!count) return;
   switch (e) {
 #define ALOHA_COL_SMALL(EE)                                                                                  \
   case EE:                                                                                                   \
-    hipLaunchKernelGGL((ntt_col_small_kernel<EE, INV, FIRST, LAST>), dim3(count << EE), dim3(256), 0, st, d_jobs, \
+    hipLaunchKernelGGL((ntt_col_small_kernel<EE, INV, FIRST, LAST, SC>), dim3(count << EE), dim3(256), 0, st, d_jobs, \
                        d_primes);                                                                            \
     break;
     ALOHA_COL_SMALL(0) ALOHA_COL_SMALL(1) ALOHA_COL_SMALL(2) ALOHA_COL_SMALL(3)
@@ -493,7 +493,7 @@ hipError_t ntt_radix2_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDe
 hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *inplace, const PrimeDev *d_primes,
                           uint32_t begin, uint32_t count, unsigned logn, bool inverse, const TileDesc *d_lds_tiles,
                           uint32_t n_lds, const TileDesc *d_glb_tiles, uint32_t n_glb, uint64_t *launches,
-                          unsigned single_max) {
+                          unsigned single_max, bool scaled) {
   if (logn < 10 || logn > 16) return hipErrorInvalidValue;
   // N = 2^12, 2^13: the limb fits one CU's LDS several times over -> one pass over memory
   // (ntt_single.hip: 3.0 / 2.6 TB/s algorithmic against 2.6 / 2.5 for the tile form below).  At
@@ -502,7 +502,7 @@ hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *
   // ALOHA_FLAG_NTT_SINGLE_14 of the handle) moves the limit: A/B timing and the on-device cross-check
   // of the two forms in the tests.
   if (logn >= 12 && logn <= 14 && logn <= single_max)
-    return ntt_single_batch(st, d_jobs + begin, d_primes, count, logn, inverse, launches);
+    return ntt_single_batch(st, d_jobs + begin, d_primes, count, logn, inverse, launches, scaled);
   const unsigned n1 = logn - 8;
   const bool col_tiles = (n1 == 8);
   const bool col_small = (n1 >= 4 && n1 <= 7);
@@ -523,9 +523,11 @@ hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *
     launch_rows<true, true, false>(st, d_jobs, d_primes, d_lds_tiles, n_lds, true, launches);
     launch_rows<true, true, false>(st, d_jobs, d_primes, d_glb_tiles, n_glb, false, launches);
     if (col_tiles) {
-      launch_cols<true, false, true>(st, inplace + begin, d_primes, count, launches);
+      if (scaled) launch_cols<true, false, true, true>(st, inplace + begin, d_primes, count, launches);
+      else launch_cols<true, false, true>(st, inplace + begin, d_primes, count, launches);
     } else if (col_small) {
-      launch_cols_small<true, false, true>(st, inplace + begin, d_primes, count, n1 - 4, launches);
+      if (scaled) launch_cols_small<true, false, true, true>(st, inplace + begin, d_primes, count, n1 - 4, launches);
+      else launch_cols_small<true, false, true>(st, inplace + begin, d_primes, count, n1 - 4, launches);
     } else {
       hipError_t e = ntt_radix2_batch(st, inplace + begin, d_primes, count, logn, 8, logn, true, true, true, launches);
       if (e != hipSuccess) return e;

@@ -282,7 +282,9 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
     vp->plans.push_back(std::move(np));
   }
   const TransformPlan *pl = plan;
-  const hipError_t e = issue(vp, [vp, pl, count, logn, inverse]() -> hipError_t {
+  bool any_scaled = false;
+  for (uint32_t i = 0; i < count && inverse; i++) any_scaled = any_scaled || jobs1[i].scaled;
+  const hipError_t e = issue(vp, [vp, pl, count, logn, inverse, any_scaled]() -> hipError_t {
     uint64_t launches = 0;
     hipError_t e = hipSuccess;
     if (pl->chunks.empty()) {
@@ -292,7 +294,8 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
         e = aloha::k::ntt_tile_batch(vp->stream, pl->d_jobs, pl->d_jobs + count, vp->d_primes, pc.limb_begin,
                                      pc.limb_count, logn, inverse, pl->d_tiles + pc.uni_off, pc.n_uni,
                                      pl->d_tiles + pc.glb_off, pc.n_glb, &launches,
-                                     (vp->flags & ALOHA_FLAG_NTT_TWO_PASS) ? 0u : (vp->flags & ALOHA_FLAG_NTT_SINGLE_14) ? 14u : 13u);
+                                     (vp->flags & ALOHA_FLAG_NTT_TWO_PASS) ? 0u : (vp->flags & ALOHA_FLAG_NTT_SINGLE_14) ? 14u : 13u,
+                                     any_scaled);
         if (e != hipSuccess) break;
       }
     }
@@ -1039,27 +1042,65 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         // vs1 is UNDEFINED afterwards; here it keeps its value.
         u64 *z = nullptr;
         ALOHA_RUN_CK(direct_store(&z));
+        // `vintt vd, .. ; vfqmul.vs vE, vd, c ; [vfqadd.vs vE, vE, a ;] vse vE, Z` with vd, vE dead afterwards: the scalar
+        // rides in the transform's last stage, the constant on its canonical result (LimbJob::sc) -- one transform job
+        // instead of a transform, a pass over the limb and a store.  Tile / single-pass kernels only (N >= 2^12).
+        unsigned skip = 0;                                         // instructions consumed besides the vintt and the vse
+        LimbJob scaled{};
+        if (!z && inv && fuse && logn >= 12 && !(vp->flags & ALOHA_FLAG_RADIX2_ONLY) && pc + 2 < ALOHA_IRAM_DEPTH) {
+          const Decoded m1 = decode_at(vp, pc + 1);
+          if (m1.funct6 == 0x01 && m1.funct3 == 1 && m1.vs1 == vd && m1.imm < 2 * q) {
+            unsigned e = m1.vd, at = pc + 2;
+            uint64_t addc = 0;
+            bool ok = (e == vd) || dead_from(vp, pc + 2, vd);
+            Decoded nx = decode_at(vp, at);
+            if (ok && nx.funct6 == 0x05 && nx.funct3 == 1 && nx.vs1 == e && nx.vd == e && nx.imm < 2 * q && at + 1 < ALOHA_IRAM_DEPTH) {
+              addc = nx.imm >= q ? nx.imm - q : nx.imm;
+              at++;
+              nx = decode_at(vp, at);
+            }
+            if (ok && nx.funct6 == 0x07 && nx.vs1 == e && dead_from(vp, at + 1, e)) {
+              u64 *zz = mem_rows(vp, nx.imm, false, csr, n / kLanes);
+              if (zz) {
+                const uint64_t c = m1.imm >= q ? m1.imm - q : m1.imm;
+                const auto &tt = vp->slots[slot].dev.tw;
+                z = zz; skip = at - pc - 1;
+                scaled.scaled = 1;
+                scaled.sc[0] = aloha::nt::mulmod(tt.w1n_inv, c, q); scaled.sc[1] = aloha::nt::shoup(scaled.sc[0], q);
+                scaled.sc[2] = aloha::nt::mulmod(tt.n_inv, c, q);   scaled.sc[3] = aloha::nt::shoup(scaled.sc[2], q);
+                scaled.addc = addc;
+              }
+            }
+          }
+        }
         const u64 *src = rd(vs1);
-        if (z && src != z && overlap(src, z, n)) z = nullptr;
+        if (z && src != z && overlap(src, z, n)) { z = nullptr; skip = 0; }
         lazy[vd].clear();
         if (z) {
           // fused `vle; vntt; vse`: join the pending transform batch unless it conflicts with it
           // (an in-place job, src == z, is fine: can_join sees only OTHER jobs' ranges)
           auto joinable = [&]() { return can_join(PK_NTT, logn, src, nullptr, z, n) && (batch.empty() || batch_inv == inv); };
           if (!joinable()) ALOHA_RUN_CK(flush());
-          if (alias[vs1] == src && dead_from(vp, pc + 2, vs1)) alias[vs1] = nullptr;   // (undefined after the transform anyway)
-          ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
+          if (alias[vs1] == src && dead_from(vp, pc + 2 + skip, vs1)) alias[vs1] = nullptr;   // (undefined after the transform anyway)
+          ALOHA_RUN_CK(before_mem_write(z, n, pc + 2 + skip));
           if (!joinable()) ALOHA_RUN_CK(flush());
-          batch.push_back(LimbJob{src, z, slot, 0});
+          if (skip) {
+            scaled.src = src; scaled.dst = z; scaled.prime = slot;
+            batch.push_back(scaled);
+            const Decoded m1 = decode_at(vp, pc + 1);
+            lazy[m1.vd].clear(); alias[m1.vd] = nullptr;
+          } else {
+            batch.push_back(LimbJob{src, z, slot, 0, {0, 0, 0, 0}, 0});
+          }
           note_rw(src, z, n);
           pend_kind = PK_NTT; batch_inv = inv; batch_logn = logn;
           alias[vd] = nullptr;
-          pc++; vp->stats.instructions++;
+          pc += 1 + skip; vp->stats.instructions += 1 + skip;
           break;
         }
         ALOHA_RUN_CK(flush());
         std::vector<LimbJob> job(1);
-        job[0] = LimbJob{src, vreg(vp, vd), slot, 0};
+        job[0] = LimbJob{src, vreg(vp, vd), slot, 0, {0, 0, 0, 0}, 0};
         ALOHA_RUN_CK(run_transforms(vp, job, logn, inv));
         alias[vd] = nullptr;
         break;
@@ -1185,7 +1226,7 @@ aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64
       if (s) return s;
       last_q = moduli[i];
     }
-    jobs[i] = LimbJob{src + ((size_t)i << log_n), dst + ((size_t)i << log_n), last_slot, 0};
+    jobs[i] = LimbJob{src + ((size_t)i << log_n), dst + ((size_t)i << log_n), last_slot, 0, {0, 0, 0, 0}, 0};
   }
   if (vp->rows_cache.size() >= kMaxPlans) vp->rows_cache.erase(vp->rows_cache.begin());
   RowsKey key;

@@ -216,18 +216,13 @@ def blocks_phase1(lo: HybridLayout, mode: str, bs=None) -> List[List[str]]:
                     f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(0, i, bi)):#x}", "vfqmul.vv v3, v0, v1",
                     "vfqadd.vv v6, v6, v3", f"vse v6, abs+{o(lo.s_base1(i, bi)):#x}"])
     x_of = (lambda i, bi: lo.s_in(1, i, bi)) if mode == "hoist" else lo.s_x    # hoisted: c1 itself, not rotated
-    for i, j in own:                                            # coefficient form
-        blk = _setq(lo.moduli[j])
-        for bi in B:
-            blk += [f"vle v0, abs+{o(x_of(i, bi)):#x}", "vintt v2, v0", f"vse v2, abs+{o(lo.s_s1(0, i, bi)):#x}"]
-        b.append(blk)
-    for i, j in own:                                            # times (Q_d/q_j)^-1 mod q_j
-        q = lo.moduli[j]
-        dig = lo.digit(j // lo.alpha)
+    for i, j in own:                                            # coefficient form, times (Q_d/q_j)^-1 mod q_j: one scaled
+        q = lo.moduli[j]                                        # inverse transform per limb (the engine folds the scalar
+        dig = lo.digit(j // lo.alpha)                           # into the transform's last stage)
         c = _inv(_prod(lo.moduli[t] for t in dig if t != j), q)
         blk = _setq(q)
         for bi in B:
-            blk += [f"vle v0, abs+{o(lo.s_s1(0, i, bi)):#x}", f"vfqmul.vs v2, v0, {c:#x}", f"vse v2, abs+{o(lo.y_slot(j, bi)):#x}"]
+            blk += [f"vle v0, abs+{o(x_of(i, bi)):#x}", "vintt v2, v0", f"vfqmul.vs v4, v2, {c:#x}", f"vse v4, abs+{o(lo.y_slot(j, bi)):#x}"]
         b.append(blk)
     return b
 
@@ -278,23 +273,19 @@ def blocks_inner(lo: HybridLayout, hoisted: bool = False, regions=None) -> List[
 
 
 def blocks_moddown_terms(lo: HybridLayout, bs=None) -> List[List[str]]:
-    """Two loops, each one batched launch: the special primes' accumulators to coefficient form (in place,
-    they are not needed again), then W = (x + floor(P/2)) * (P/p_k)^-1 = x*c + floor(P/2)*c as a one-term sum
-    with a constant."""
+    """W = (iNTT(acc) + floor(P/2)) * (P/p_k)^-1 = iNTT(acc)*c + floor(P/2)*c: a transform, a scalar and a constant, which
+    the engine runs as one scaled inverse transform per accumulator (one batched launch pair for the phase)."""
     b, o, B = [], lo.off, (range(lo.B) if bs is None else bs)
     acc = lambda k, c, bi: o(lo.s_acc(lo.owned_all.index(lo.L + k), c, bi))
-    for k in lo.owned_sp:
-        blk = _setq(lo.specials[k])
-        for c in range(2):
-            for bi in B:
-                blk += [f"vle v0, abs+{acc(k, c, bi):#x}", "vintt v2, v0", f"vse v2, abs+{acc(k, c, bi):#x}"]
-        b.append(blk)
-    for k in lo.owned_sp:
+    for k in lo.owned_sp:                                       # one scaled inverse transform per accumulator
         p = lo.specials[k]
         cinv = _inv(lo.P // p, p)
+        blk = _setq(p)
         for c in range(2):
             for bi in B:
-                b.append(_setq(p) + _scalar_sum([acc(k, c, bi)], [cinv], o(lo.w_slot(k, c, bi)), plus=(lo.half % p) * cinv % p))
+                blk += [f"vle v0, abs+{acc(k, c, bi):#x}", "vintt v2, v0", f"vfqmul.vs v4, v2, {cinv:#x}",
+                        f"vfqadd.vs v4, v4, {(lo.half % p) * cinv % p:#x}", f"vse v4, abs+{o(lo.w_slot(k, c, bi)):#x}"]
+        b.append(blk)
     return b
 
 
@@ -357,11 +348,9 @@ def blocks_rescale(lo: HybridLayout) -> List[List[List[str]]]:
         blk = _setq(qL)
         for c in range(2):
             for bi in B:
-                blk += [f"vle v0, abs+{o(lo.s_in(c, iL, bi)):#x}", "vintt v2, v0", f"vse v2, abs+{o(lo.s_s1(c, iL, bi)):#x}"]
+                blk += [f"vle v0, abs+{o(lo.s_in(c, iL, bi)):#x}", "vintt v2, v0", "vfqmul.vs v4, v2, 0x1",
+                        f"vfqadd.vs v4, v4, {half:#x}", f"vse v4, abs+{o(lo.rescale_slot(c, bi)):#x}"]
         first.append(blk)
-        for c in range(2):
-            for bi in B:
-                first.append(_setq(qL) + _scalar_sum([o(lo.s_s1(c, iL, bi))], [1], o(lo.rescale_slot(c, bi)), plus=half))
     for i, j in enumerate(lo.owned_ct):
         if j == L - 1:
             continue

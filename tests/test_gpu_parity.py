@@ -438,7 +438,7 @@ def _random_program(rng, n, primes, nslots, length):
         return f"src0+{int(rng.integers(nslots)) * 8 * n:#x}"
 
     for _ in range(length):
-        op = rng.choice(["vle", "vle", "vse", "vv", "vs", "un", "perm", "ntt", "setq", "dot", "sdot", "stores"])
+        op = rng.choice(["vle", "vle", "vse", "vv", "vs", "un", "perm", "ntt", "setq", "dot", "sdot", "stores", "iscale"])
         vd = int(rng.choice(regs))
         if op == "vle":
             lines.append(f"vle v{vd}, {slot()}"); defined.add(vd)
@@ -507,6 +507,16 @@ def _random_program(rng, n, primes, nslots, length):
                 lines.append(f"vse v{acc}, {slot()}")
             elif choice == 1:                                # a lazy value read by another op: must be evaluated first
                 lines.append(f"vfqsub.vs v2, v{acc}, {int(rng.integers(1, 1 << 59)):#x}"); defined.add(2)
+        elif op == "iscale":                                 # inverse transform, scalar, [constant], store: one scaled transform job
+            for _ in range(int(rng.integers(1, 4))):
+                e = int(rng.choice([2, 4]))
+                lines += [f"vle v0, {slot()}", "vintt v2, v0", f"vfqmul.vs v{e}, v2, {int(rng.integers(1, 1 << 60)):#x}"]
+                if rng.integers(2):
+                    lines.append(f"vfqadd.vs v{e}, v{e}, {int(rng.integers(0, 1 << 60)):#x}")
+                lines.append(f"vse v{e}, {slot()}")
+            defined.difference_update({0, 2, 4})
+            if rng.integers(3) == 0:                         # ... or the product is read again afterwards: no fusion
+                defined.add(e)
         elif op == "stores":                                 # several sums stored back to back (one deferred launch), with hazards
             for _ in range(int(rng.integers(2, 4))):
                 lines += [f"vle v0, {slot()}", f"vle v1, {slot()}", "vfqmul.vv v6, v0, v1", f"vle v0, {slot()}",
@@ -515,6 +525,49 @@ def _random_program(rng, n, primes, nslots, length):
     for r in sorted(defined):                                # flush every live register to memory
         lines.append(f"vse v{r}, src0+{(nslots + r) * 8 * n:#x}")
     return "\n".join(lines + ["break"])
+
+
+@pytest.mark.parametrize("logn", [11, 12, 13, 14, 15, 16])
+def test_scaled_inverse_transform_idiom_matches_oracle(engine, logn):
+    """`vle; vintt; vfqmul.vs c; [vfqadd.vs a;] vse` leaves the sequencer as ONE transform job whose last stage carries
+    the scalar (and whose canonical result gets the constant): every kernel form of the inverse transform (single pass,
+    small-N column kernels, the N = 2^16 column kernel; N = 2^11 stays unfused), several primes in one batch, scalars
+    and constants at the edges, and variants the fusion must refuse (the transform's register read again later)."""
+    n = 1 << logn
+    rows = n // 128
+    rng = np.random.default_rng(300 + logn)
+    primes = [oracle.nth_prime(max(logn, 13), i) for i in range(3)]
+    nin = 6
+    data = np.stack([rng.integers(0, 1 << 60, n, dtype=np.uint64) for _ in range(nin)])
+    lines = [f"vsetvl {64 * n:#x}"]
+    off = lambda slot: slot * 8 * n
+    out = nin
+    for i in range(nin):
+        q = primes[i % 3]
+        c = [1, q - 1, int(rng.integers(1, q)), (1 << 60) - 1, int(rng.integers(1, q)), 2][i]
+        e = 2 if i % 2 else 4
+        lines += [f"vsetq {q:#x}", f"vle v0, src0+{off(i):#x}", "vintt v2, v0", f"vfqmul.vs v{e}, v2, {c:#x}"]
+        if i % 3:
+            lines.append(f"vfqadd.vs v{e}, v{e}, {[0, q - 1, int(rng.integers(0, q))][i % 3]:#x}")
+        lines.append(f"vse v{e}, src0+{off(out):#x}")
+        out += 1
+    # refused: the untransformed... the transform result is read again (v2 stored as well), and a vfqsub.vs in the chain
+    q = primes[0]
+    lines += [f"vsetq {q:#x}", f"vle v0, src0+{off(0):#x}", "vintt v2, v0", "vfqmul.vs v4, v2, 0x5", f"vse v4, src0+{off(out):#x}",
+              f"vse v2, src0+{off(out + 1):#x}"]
+    out += 2
+    lines += [f"vle v0, src0+{off(1):#x}", "vintt v2, v0", "vfqmul.vs v4, v2, 0x7", "vfqsub.vs v4, v4, 0x3", f"vse v4, src0+{off(out):#x}"]
+    out += 1
+    words = isa.assemble("\n".join(lines + ["break"]))
+    o = oracle.OracleVP(spm_rows=out * rows, ksk_rows=1)
+    res = []
+    for vp in (engine, o):
+        vp.write(SPM, 0, np.zeros(out * n, np.uint64)); vp.write(SPM, 0, data.reshape(-1))
+        vp.load_isram(0, np.zeros((isa.IRAM_DEPTH, 3), np.uint32)); vp.load_isram(0, words)
+        assert vp.run(0, src0=0) == 0
+        vp.sync()
+        res.append(vp.read(SPM, 0, out * n))
+    assert np.array_equal(res[0], res[1])
 
 
 @pytest.mark.parametrize("logn", [10, 13, 16])
