@@ -271,6 +271,17 @@ struct TwStepMixT {                // the first NPRE entries preloaded, the rest
   }
 };
 
+template <int NPRE>
+struct TwStepMixHi {               // the LAST NPRE entries preloaded (the inverse step uses sub-stage 3 first), the rest read at use
+  const tw_t (&r)[15];
+  ctw_t blk;
+  int kh;
+  __device__ __forceinline__ tw_t operator()(int ss, int g) const {
+    const int idx = (1 << ss) - 1 + g;
+    return idx >= 15 - NPRE ? r[idx] : load_tw(blk + (16 << ss) + (kh << ss) + g);
+  }
+};
+
 // in-wave LDS hand-off: LDS instructions of one wave execute in issue order, so lanes of the
 // same wave need no s_barrier between a ds_write and a dependent ds_read -- only the compiler
 // must keep the order.

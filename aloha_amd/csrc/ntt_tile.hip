@@ -118,9 +118,22 @@ __global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict_
       st_stream(&(dst + ((size_t)jj << 8))[offB], LAST ? canon_any(v[jj], q, nq, (u32)pr->m.kc) : v[jj]);
     }
   } else {
+#ifndef ALOHA_INV_PRELOAD
+#define ALOHA_INV_PRELOAD 15       // per-lane twiddles of the first inverse step issued before the data loads (0 / 8 / 15: 2.38 / 2.38 / 2.44 M inverse NTT/s)
+#endif
+    tw_t twb[15];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++)
+#pragma unroll
+      for (int g = 0; g < (1 << ss); g++)
+        if ((1 << ss) - 1 + g >= 15 - ALOHA_INV_PRELOAD) {
+          const gtw_t p = (gtw_t)blk + (16 << ss) + (slow << ss) + g;
+          twb[(1 << ss) - 1 + g].w = p->w;
+          twb[(1 << ss) - 1 + g].wp = p->wp;
+        }
 #pragma unroll
     for (int jj = 0; jj < 16; jj++) v[jj] = ld_stream(&(src + ((size_t)jj << 8))[offB]);
-    inv_radix16<false, FIRST ? INV_IN : INV_MID, false>(v, TwStepB{blk, (int)slow}, q, nq);
+    inv_radix16<false, FIRST ? INV_IN : INV_MID, false>(v, TwStepMixHi<ALOHA_INV_PRELOAD>{twb, blk, (int)slow}, q, nq);
 #pragma unroll
     for (int jj = 0; jj < 16; jj++) sdata[col * PITCH + 16 * slow + jj] = v[jj];
     __syncthreads();
@@ -329,12 +342,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INV ? ALOHA_
     }
 #endif
   } else {
+#ifndef ALOHA_INV_ROW_PRELOAD
+#define ALOHA_INV_ROW_PRELOAD 15   // (with the column pass at 15: 0 / 12 / 15 = 2.44 / 2.45 / 2.48 M)
+#endif
+    tw_t twb[15];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++)
+#pragma unroll
+      for (int g = 0; g < (1 << ss); g++)
+        if ((1 << ss) - 1 + g >= 15 - ALOHA_INV_ROW_PRELOAD) {
+          const gtw_t p = (gtw_t)blkB + (16 << ss) + (khB << ss) + g;
+          twb[(1 << ss) - 1 + g].w = p->w;
+          twb[(1 << ss) - 1 + g].wp = p->wp;
+        }
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) lds[ldsA + 17 * kk] = v[kk];
     wave_lds_fence();
 #pragma unroll
     for (int jj = 0; jj < 16; jj++) v[jj] = lds[ldsB + jj];
-    inv_radix16<false, FIRST ? INV_IN : INV_MID, false>(v, TwStepB{blkB, (int)khB}, q, nq);
+    inv_radix16<false, FIRST ? INV_IN : INV_MID, false>(v, TwStepMixHi<ALOHA_INV_ROW_PRELOAD>{twb, blkB, (int)khB}, q, nq);
   }
   // back to the A mapping: second inverse step / 128-byte-segment stores
 #if ALOHA_ABLATE != 4   // timing experiment 4: skip the transpose back (stores land in the wrong order)
