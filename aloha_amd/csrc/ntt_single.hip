@@ -61,6 +61,39 @@ struct TwPlain {
   __device__ __forceinline__ tw_t operator()(int ss, int g) const { return load_tw(tab + (base << ss) + (a << ss) + g); }
 };
 
+template <int NPRE, bool HI>      // NPRE entries from registers: the first ones (forward) or the last ones (inverse: sub-stage 3 first)
+struct TwPlainMix {
+  const tw_t (&r)[15];
+  TwPlain rest;
+  __device__ __forceinline__ tw_t operator()(int ss, int g) const {
+    const int idx = (1 << ss) - 1 + g;
+    return (HI ? idx >= 15 - NPRE : idx < NPRE) ? r[idx] : rest(ss, g);
+  }
+};
+template <int NPRE, bool HI>
+__device__ __forceinline__ void preload_tw(tw_t (&r)[15], ctw_t tab, uint32_t base, uint32_t a) {
+#pragma unroll
+  for (int ss = 0; ss < 4; ss++)
+#pragma unroll
+    for (int g = 0; g < (1 << ss); g++) {
+      const int idx = (1 << ss) - 1 + g;
+      if (HI ? idx >= 15 - NPRE : idx < NPRE) {
+        const gtw_t p = (gtw_t)tab + (base << ss) + (a << ss) + g;
+        r[idx].w = p->w;
+        r[idx].wp = p->wp;
+      }
+    }
+}
+// Per-lane twiddles of the NEXT radix-16 step issued before the current one, as many as the register budget of
+// 4 waves per SIMD allows: forward 0 at N = 2^12 (121 VGPRs as it is), 7 above (N = 2^13: 20.3 -> 21.4 M NTT/s;
+// 15 spills: 15.2 M); inverse: see ALOHA_SINGLE_PRE_INV.
+#ifndef ALOHA_SINGLE_PRE
+#define ALOHA_SINGLE_PRE (LOGN == 12 ? 0 : 7)
+#endif
+#ifndef ALOHA_SINGLE_PRE_INV
+#define ALOHA_SINGLE_PRE_INV 4   // (0 / 4 / 8: N = 2^12 43.8 / 44.8 / 39.5, N = 2^13 19.5 / 19.9 / 19.4 M inverse NTT/s)
+#endif
+
 #ifndef ALOHA_SINGLE_WAVES
 #define ALOHA_SINGLE_WAVES 4   // at least 4 waves per SIMD (<= 128 VGPRs): two workgroups per CU at N = 2^13
 #endif
@@ -98,11 +131,14 @@ __global__ __launch_bounds__((1 << LOGN) / 16) __attribute__((amdgpu_waves_per_e
     static_assert(B3 <= 16 && B4 <= 16 && B5 <= 16, "forward lazy range overflows");
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = ld_stream(src + r * T + t);
+    tw_t tw1[15], tw2[15];
+    preload_tw<ALOHA_SINGLE_PRE, false>(tw1, tab, 16, a1);
     fwd_radix16<true, B0>(v, TwPlain{tab, 1, 0}, q, nq);                       // stages 0..3
     exchange(L0, L1, false);
-    fwd_radix16<false, B1>(v, TwPlain{tab, 16, a1}, q, nq);                    // stages 4..7
+    preload_tw<ALOHA_SINGLE_PRE, false>(tw2, tab, 256, a2);
+    fwd_radix16<false, B1>(v, TwPlainMix<ALOHA_SINGLE_PRE, false>{tw1, TwPlain{tab, 16, a1}}, q, nq);   // stages 4..7
     exchange(L1, L2, true);
-    fwd_radix16<false, B2>(v, TwPlain{tab, 256, a2}, q, nq);                   // stages 8..11
+    fwd_radix16<false, B2>(v, TwPlainMix<ALOHA_SINGLE_PRE, false>{tw2, TwPlain{tab, 256, a2}}, q, nq);  // stages 8..11
     exchange(L2, L3, false);
     const u64 fourq = q << 2;
     if (E == 1) {                                              // stage 12: pairs (2h, 2h+1), group e >> 1 = h*T + t
@@ -159,10 +195,13 @@ __global__ __launch_bounds__((1 << LOGN) / 16) __attribute__((amdgpu_waves_per_e
         gs_bfly<false>(v[2 * h], v[2 * h + 1], w.w, w.wp, nq, fourq);
       }
     }
+    tw_t tw2[15], tw1[15];
+    preload_tw<ALOHA_SINGLE_PRE_INV, true>(tw2, tab, 256, a2);
     exchange(L3, L2, false);
-    inv_radix16<false, E ? INV_MID : INV_IN, false>(v, TwPlain{tab, 256, a2}, q, nq);   // stages 11..8
+    preload_tw<ALOHA_SINGLE_PRE_INV, true>(tw1, tab, 16, a1);
+    inv_radix16<false, E ? INV_MID : INV_IN, false>(v, TwPlainMix<ALOHA_SINGLE_PRE_INV, true>{tw2, TwPlain{tab, 256, a2}}, q, nq);   // stages 11..8
     exchange(L2, L1, true);
-    inv_radix16<false, INV_MID, false>(v, TwPlain{tab, 16, a1}, q, nq);                // stages 7..4
+    inv_radix16<false, INV_MID, false>(v, TwPlainMix<ALOHA_SINGLE_PRE_INV, true>{tw1, TwPlain{tab, 16, a1}}, q, nq);                // stages 7..4
     exchange(L1, L0, false);
     const LastScale ls = last_scale<SC>(&jobs[blockIdx.x], pr);
     inv_radix16<true, INV_MID, true>(v, TwPlain{tab, 1, 0}, q, nq, ls.w, ls.ni, ls.nip);   // stages 3..0, times N^-1 (times the job's scalar)
