@@ -789,3 +789,44 @@ def test_poly_mul_program_config3(engine):
         else:
             acc -= int(a[0][i]) * int(b[0][j - i + n])
     assert int(res[0][j]) == acc % q
+
+
+def test_recorded_runs_survive_cache_evictions():
+    """Recorded launch lists point to cached device job arrays and transform plans; both caches evict (512 arrays,
+    128 plans).  700 distinct programs push everything of the first ones out; running those again -- on new data --
+    must notice (the epoch) and sequence afresh instead of replaying launches that point to freed memory."""
+    n, rows = 1024, 8
+    q = oracle.nth_prime(13, 0)
+    rng = np.random.default_rng(5)
+
+    def prog(i):
+        return isa.assemble("\n".join([
+            f"vsetvl {64 * n:#x}", f"vsetq {q:#x}",
+            "vle v0, src0+0x0", f"vfqmul.vs v2, v0, {i + 2:#x}", f"vse v2, src0+{2 * 8 * n:#x}",
+            f"vle v0, src0+{8 * n:#x}", f"vfqmul.vs v2, v0, {3 * i + 5:#x}", f"vse v2, src0+{3 * 8 * n:#x}",
+            "vle v0, src0+0x0", "vntt v2, v0", f"vse v2, src0+{4 * 8 * n:#x}",
+            f"vle v0, src0+{8 * n:#x}", "vntt v2, v0", f"vse v2, src0+{5 * 8 * n + (i % 200) * 1024:#x}", "break"]))   # 200 distinct plans
+
+    S = 48                                                       # limb slots of memory
+    with avp.VP(spm_rows=S * rows, ksk_rows=1, max_log_n=10) as vp:
+        o = oracle.OracleVP(spm_rows=S * rows, ksk_rows=1)
+
+        def check(i):
+            data = rng.integers(0, q, 2 * n, dtype=np.uint64)
+            out = []
+            for e in (vp, o):
+                e.write(SPM, 0, np.zeros(S * n, np.uint64)); e.write(SPM, 0, data)
+                e.load_isram(0, prog(i))
+                assert e.run(0, src0=0) == 0
+                e.sync()
+                out.append(e.read(SPM, 0, S * n))
+            assert np.array_equal(out[0], out[1]), i
+
+        for i in (0, 1, 2):
+            check(i); check(i)                                   # recorded, then replayed
+        for i in range(3, 700):                                  # evict
+            vp.load_isram(0, prog(i))
+            assert vp.run(0, src0=0) == 0
+        vp.sync()
+        for i in (0, 1, 2, 699, 0):
+            check(i)
