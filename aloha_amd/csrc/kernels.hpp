@@ -149,6 +149,22 @@ hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *
                           unsigned single_max = 13,    // largest log2 N transformed by the single-pass kernels (0: never)
                           bool scaled = false);       // inverse only: some job carries its own last-stage scalar (LimbJob::scaled)
 
+// Fused forward transform for N = 2^16 (ntt_tile.hip, ntt_fused_fwd_kernel): both passes in ONE persistent launch,
+// the intermediate handed from column tiles to row tiles through the Infinity Cache.  Needs a batch whose row tiles
+// are all bundle tiles (>= 4 limbs per prime adjacent).  d_ctl: fused_ctl_words(count) u32 of device memory (zeroed by
+// the launcher): ticket counters and one arrival counter per limb.  d_status: one sticky u32 owned by the caller,
+// non-zero after a launch gave up on a bounded wait (its output is then incomplete).
+constexpr uint32_t kFusedShards = 32;      // ticket counters (one 128-byte line each)
+constexpr uint32_t kFusedCtrStride = 16;   // u32 words between arrival counters (64 bytes)
+constexpr uint32_t kFusedStatsWord = kFusedShards * 32;   // ctl[kFusedStatsWord + 0/1]: tiles that waited / their poll iterations
+void build_fused_schedule(const std::vector<TileDesc> &uni_tiles, unsigned log_rows, unsigned delay,
+                          std::vector<uint64_t> &tickets);
+size_t fused_ctl_words(uint32_t count);
+uint32_t fused_workgroups_per_cu();      // resident workgroups of the fused kernel per CU (occupancy query)
+hipError_t ntt_fused_fwd(hipStream_t st, const LimbJob *d_jobs, const LimbJob *d_inplace, const PrimeDev *d_primes,
+                         const TileDesc *d_tiles, const uint64_t *d_tickets, uint32_t npos, uint32_t count,
+                         uint32_t *d_ctl, uint32_t *d_status, uint32_t workgroups, uint64_t *launches);
+
 // Single-pass transforms for N = 2^12 .. 2^14 (the limb stays in one CU's LDS: one read + one write of
 // the limb, ntt_single.hip); d_jobs = the {src, dst} entries of the limbs to transform.
 hipError_t ntt_single_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,

@@ -62,9 +62,15 @@ struct TransformPlan {           // device-side description of one batched trans
   std::vector<PlanChunk> chunks; // empty => radix-2 stage launches only
   LimbJob *d_jobs = nullptr;
   TileDesc *d_tiles = nullptr;
+  // fused forward transform (N = 2^16, every row tile a bundle tile): ticket list + control words (kernels.hpp)
+  uint64_t *d_tickets = nullptr;
+  uint32_t *d_ctl = nullptr;
+  uint32_t npos = 0;
   ~TransformPlan() {
     if (d_jobs) (void)hipFree(d_jobs);
     if (d_tiles) (void)hipFree(d_tiles);
+    if (d_tickets) (void)hipFree(d_tickets);
+    if (d_ctl) (void)hipFree(d_ctl);
   }
 };
 
@@ -97,6 +103,11 @@ struct aloha_vp {
   std::vector<RowsKey> rows_cache;
   std::vector<std::pair<std::vector<uint8_t>, void *>> blobs;   // cached device copies of batched job arrays
   uint32_t chunk_limbs = 0;      // limbs per chunk of a batched transform (0 = whole batch; chunking did not pay)
+  // fused single-launch forward transform at N = 2^16 (ntt_tile.hip): batches of at least fused_min limbs
+  uint32_t fused_min = 0, fused_delay = 8, fused_wgs = 0;   // off by default: measured slower than two launches
+  uint32_t *d_fused_status = nullptr;                // sticky: non-zero after a fused launch gave up on a bounded wait
+  bool fused_stats = false;                          // ALOHA_NTT_FUSED_STATS: print the scheduler's wait counts after every fused launch
+  bool fused_unchecked = false;                      // a fused launch ran since the status word was last read
   // CKKS encoder: tables per ring size, staging buffers
   struct EncTab { aloha::k::EncodeTables t{}; void *alloc = nullptr; };
   std::map<unsigned, EncTab> enc_tables;
@@ -123,6 +134,18 @@ struct aloha_vp {
 
 namespace {
 
+// Every entry point that touches HIP runs with the handle's device current and restores the caller's on return: in a
+// process that sees several GPUs (torch switching devices, handles on different devices) allocations and launches would
+// otherwise land on whatever device the calling thread had selected last.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const aloha_vp *vp);
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 aloha_status fail(aloha_vp *vp, aloha_status s, const char *fmt, ...) {
   if (vp) {
     char buf[512];
@@ -133,6 +156,11 @@ aloha_status fail(aloha_vp *vp, aloha_status s, const char *fmt, ...) {
     vp->err = buf;
   }
   return s;
+}
+
+DeviceGuard::DeviceGuard(const aloha_vp *vp) {
+  if (!vp) return;
+  if (hipGetDevice(&prev) == hipSuccess && prev != vp->device) switched = hipSetDevice(vp->device) == hipSuccess;
 }
 
 #define HIPCK(vp, expr)                                                                     \
@@ -231,6 +259,19 @@ aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
   return ALOHA_OK;
 }
 
+// After a synchronisation: did a fused transform give up on one of its bounded waits?  (It cannot in a correct
+// schedule -- see ntt_fused_fwd_kernel -- but a wait that can be bounded is, and the bound is reported.)
+aloha_status check_fused(aloha_vp *vp) {
+  if (!vp->fused_unchecked) return ALOHA_OK;
+  uint32_t st = 0;
+  HIPCK(vp, hipMemcpyAsync(&st, vp->d_fused_status, 4, hipMemcpyDeviceToHost, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  vp->fused_unchecked = false;
+  if (!st) return ALOHA_OK;
+  HIPCK(vp, hipMemsetAsync(vp->d_fused_status, 0, 4, vp->stream));
+  return fail(vp, ALOHA_ERR_DEVICE, "fused N=2^16 transform gave up on a bounded wait (%u waits): its output is incomplete", st);
+}
+
 // Batched transform of `count` limbs described by (src, dst, slot); the workhorse behind both
 // the vntt/vintt instructions (count = 1) and aloha_vp_ntt_rows.
 aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, unsigned logn, bool inverse) {
@@ -267,11 +308,23 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
       np->chunks.push_back(pc);
     }
     if (!tiled) np->chunks.clear();
+    // N = 2^16, one chunk, every row tile a bundle tile, a batch large enough to fill the persistent grid: the forward
+    // transform runs as ONE launch with the intermediate handed over through the Infinity Cache (ntt_tile.hip)
+    std::vector<uint64_t> tickets;
+    if (logn == 16 && np->chunks.size() == 1 && np->chunks[0].n_glb == 0 && vp->fused_min && count >= vp->fused_min &&
+        !(vp->flags & ALOHA_FLAG_NTT_TWO_PASS))
+      aloha::k::build_fused_schedule(tiles, logn - 8, vp->fused_delay, tickets);
     HIPCK(vp, hipMalloc(&np->d_jobs, np->jobs.size() * sizeof(LimbJob)));
     HIPCK(vp, hipMemcpyAsync(np->d_jobs, np->jobs.data(), np->jobs.size() * sizeof(LimbJob), hipMemcpyHostToDevice, vp->stream));
     if (!tiles.empty()) {
       HIPCK(vp, hipMalloc(&np->d_tiles, tiles.size() * sizeof(TileDesc)));
       HIPCK(vp, hipMemcpyAsync(np->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, vp->stream));
+    }
+    if (!tickets.empty()) {
+      np->npos = (uint32_t)tickets.size();
+      HIPCK(vp, hipMalloc(&np->d_tickets, tickets.size() * 8));
+      HIPCK(vp, hipMemcpyAsync(np->d_tickets, tickets.data(), tickets.size() * 8, hipMemcpyHostToDevice, vp->stream));
+      HIPCK(vp, hipMalloc(&np->d_ctl, aloha::k::fused_ctl_words(count) * 4));
     }
     HIPCK(vp, hipStreamSynchronize(vp->stream));    // pageable sources go out of scope
     if (vp->plans.size() >= kMaxPlans) {            // evict the oldest; its kernels have drained (sync above)
@@ -289,6 +342,17 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
     hipError_t e = hipSuccess;
     if (pl->chunks.empty()) {
       e = aloha::k::ntt_radix2_batch(vp->stream, pl->d_jobs, vp->d_primes, count, logn, 0, logn, inverse, true, true, &launches);
+    } else if (!inverse && pl->d_tickets) {
+      e = aloha::k::ntt_fused_fwd(vp->stream, pl->d_jobs, pl->d_jobs + count, vp->d_primes, pl->d_tiles + pl->chunks[0].uni_off,
+                                  pl->d_tickets, pl->npos, count, pl->d_ctl, vp->d_fused_status, vp->fused_wgs, &launches);
+      vp->fused_unchecked = true;
+      vp->stats.fused_launches++;
+      if (e == hipSuccess && vp->fused_stats) {        // debugging aid: synchronises
+        uint32_t w[2] = {0, 0};
+        if (hipMemcpyAsync(w, pl->d_ctl + aloha::k::kFusedStatsWord, 8, hipMemcpyDeviceToHost, vp->stream) == hipSuccess &&
+            hipStreamSynchronize(vp->stream) == hipSuccess)
+          fprintf(stderr, "aloha fused ntt: %u limbs, %u positions, %u tiles waited, %u poll iterations\n", count, pl->npos, w[0], w[1]);
+      }
     } else {
       for (const PlanChunk &pc : pl->chunks) {
         e = aloha::k::ntt_tile_batch(vp->stream, pl->d_jobs, pl->d_jobs + count, vp->d_primes, pc.limb_begin,
@@ -366,6 +430,21 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   vp->max_logn = cfg->max_log_n;
   if (const char *e = getenv("ALOHA_NTT_CHUNK")) vp->chunk_limbs = (uint32_t)strtoul(e, nullptr, 10);
   vp->run_cache_on = !getenv("ALOHA_NO_RUN_CACHE");          // (A/B switch: every run goes through the sequencer again)
+  // fused single-launch forward transform (N = 2^16), an experiment kept behind a switch: ALOHA_NTT_FUSED = the smallest
+  // batch it serves (unset or 0: never);
+  // ALOHA_NTT_FUSED_DELAY = limb groups between a column tile and the row tiles that read it;
+  // ALOHA_NTT_FUSED_WGS = workgroups per CU (persistent; default and limit: what LDS and registers admit)
+  if (const char *e = getenv("ALOHA_NTT_FUSED")) vp->fused_min = (uint32_t)strtoul(e, nullptr, 10);
+  vp->fused_stats = getenv("ALOHA_NTT_FUSED_STATS") != nullptr;
+  if (const char *e = getenv("ALOHA_NTT_FUSED_DELAY")) vp->fused_delay = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
+  {
+    uint32_t per_cu = aloha::k::fused_workgroups_per_cu();
+    if (const char *e = getenv("ALOHA_NTT_FUSED_WGS")) per_cu = std::min(per_cu, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));
+    vp->fused_wgs = (uint32_t)prop.multiProcessorCount * per_cu;
+    // ALOHA_NTT_FUSED_MODE=persistent: persistent workgroups drawing tickets; default: one workgroup per ticket
+    const char *m = getenv("ALOHA_NTT_FUSED_MODE");
+    if (!(m && !strcmp(m, "persistent"))) vp->fused_wgs = 0;
+  }
   vp->inst.assign(ALOHA_IRAM_DEPTH, 0);
   vp->imm.assign(ALOHA_IRAM_DEPTH, 0);
   auto bail = [&](const char *what) {
@@ -373,6 +452,9 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
     aloha_vp_destroy(vp);
     return ALOHA_ERR_DEVICE;
   };
+  int prev_device = -1;
+  (void)hipGetDevice(&prev_device);
+  struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev_device};   // the caller's device is current again on return
   if (hipSetDevice(vp->device) != hipSuccess) return bail("hipSetDevice");
   if (cfg->stream) vp->stream = (hipStream_t)cfg->stream;
   else {
@@ -385,6 +467,8 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   if (hipMalloc(&vp->d_vreg, vreg_bytes) != hipSuccess) return bail("hipMalloc(vreg)");
   if (hipMalloc(&vp->d_scratch, (size_t)8 << vp->max_logn) != hipSuccess) return bail("hipMalloc(scratch)");
   if (hipMalloc(&vp->d_primes, kMaxPrimes * sizeof(PrimeDev)) != hipSuccess) return bail("hipMalloc(primes)");
+  if (hipMalloc(&vp->d_fused_status, 4) != hipSuccess) return bail("hipMalloc(status)");
+  if (hipMemsetAsync(vp->d_fused_status, 0, 4, vp->stream) != hipSuccess) return bail("memset");
   // the RTL's memories power up as X; give them a defined 0 instead
   if (hipMemsetAsync(vp->d_spm, 0, (vp->spm_rows ? vp->spm_rows : 1) * (size_t)ALOHA_ROW_BYTES, vp->stream) != hipSuccess) return bail("memset");
   if (hipMemsetAsync(vp->d_ksk, 0, (vp->ksk_rows ? vp->ksk_rows : 1) * (size_t)ALOHA_ROW_BYTES, vp->stream) != hipSuccess) return bail("memset");
@@ -396,6 +480,7 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
 
 void aloha_vp_destroy(aloha_vp *vp) {
   if (!vp) return;
+  DeviceGuard dev_guard(vp);
   if (vp->stream) (void)hipStreamSynchronize(vp->stream);
   for (auto &s : vp->slots) if (s.d_tables) (void)hipFree(s.d_tables);
   if (vp->d_spm) (void)hipFree(vp->d_spm);
@@ -406,6 +491,7 @@ void aloha_vp_destroy(aloha_vp *vp) {
   vp->plans.clear();
   for (auto &b : vp->blobs) if (b.second) (void)hipFree(b.second);
   for (auto &e : vp->enc_tables) if (e.second.alloc) (void)hipFree(e.second.alloc);
+  if (vp->d_fused_status) (void)hipFree(vp->d_fused_status);
   if (vp->d_enc_in) (void)hipFree(vp->d_enc_in);
   if (vp->d_enc_work) (void)hipFree(vp->d_enc_work);
   if (vp->own_stream && vp->stream) (void)hipStreamDestroy(vp->stream);
@@ -421,6 +507,7 @@ static u64 *space_ptr(aloha_vp *vp, int space, uint64_t row, uint64_t bytes) {
 
 aloha_status aloha_vp_write(aloha_vp *vp, int space, uint64_t row, const void *src, uint64_t bytes) {
   if (!vp || !src) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
   u64 *p = space_ptr(vp, space, row, bytes);
   if (!p) return fail(vp, ALOHA_ERR_ADDR, "write: rows [%llu, +%llu B) outside space %d", (u64)row, (u64)bytes, space);
   HIPCK(vp, hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, vp->stream));
@@ -430,11 +517,12 @@ aloha_status aloha_vp_write(aloha_vp *vp, int space, uint64_t row, const void *s
 
 aloha_status aloha_vp_read(aloha_vp *vp, int space, uint64_t row, void *dst, uint64_t bytes) {
   if (!vp || !dst) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
   u64 *p = space_ptr(vp, space, row, bytes);
   if (!p) return fail(vp, ALOHA_ERR_ADDR, "read: rows [%llu, +%llu B) outside space %d", (u64)row, (u64)bytes, space);
   HIPCK(vp, hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, vp->stream));
   HIPCK(vp, hipStreamSynchronize(vp->stream));
-  return ALOHA_OK;
+  return check_fused(vp);
 }
 
 void *aloha_vp_device_ptr(aloha_vp *vp, int space, uint64_t row) {
@@ -481,8 +569,9 @@ aloha_status aloha_vp_load_isram_hex(aloha_vp *vp, uint32_t base_pc, const char 
 
 aloha_status aloha_vp_sync(aloha_vp *vp) {
   if (!vp) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
   HIPCK(vp, hipStreamSynchronize(vp->stream));
-  return ALOHA_OK;
+  return check_fused(vp);
 }
 
 }  // extern "C" (reopened after the sequencer)
@@ -565,6 +654,7 @@ aloha_status device_blob(aloha_vp *vp, const void *host, size_t bytes, const voi
 extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
                                      uint64_t rslt_row, uint64_t ksk_row, uint64_t step) {
   if (!vp) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
   const uint64_t csr[4] = {src0_row, src1_row, rslt_row, ksk_row};
   hipStream_t st = vp->stream;
   const bool fuse = !(vp->flags & ALOHA_FLAG_NO_FUSION);
@@ -1204,6 +1294,7 @@ extern "C" {
 aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64_t src_row, uint32_t log_n,
                                const uint64_t *moduli, uint32_t count, int inverse) {
   if (!vp || !moduli) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
   if (log_n < 10 || log_n > 16) return fail(vp, ALOHA_ERR_VL, "ntt_rows: log_n = %u", log_n);
   const uint64_t rows_per_limb = (1ull << log_n) / kLanes;
   const uint64_t bytes = (uint64_t)count * rows_per_limb * ALOHA_ROW_BYTES;
@@ -1294,6 +1385,7 @@ extern "C" {
 aloha_status aloha_vp_encode(aloha_vp *vp, int space, uint64_t dst_row, const double *host_re_im, uint32_t nplain,
                              uint32_t log_n, const uint64_t *moduli, uint32_t nlimbs, double scale) {
   if (!vp || !host_re_im || !moduli || !nplain || !nlimbs || !(scale > 0)) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
   if (log_n < 10 || log_n > 16) return fail(vp, ALOHA_ERR_VL, "encode: log_n = %u", log_n);
   for (uint32_t l = 0; l < nlimbs; l++)
     if (!modulus_ok(moduli[l])) return fail(vp, ALOHA_ERR_MODULUS, "encode: modulus[%u] = %#llx", l, (u64)moduli[l]);
@@ -1325,6 +1417,7 @@ aloha_status aloha_vp_encode(aloha_vp *vp, int space, uint64_t dst_row, const do
 aloha_status aloha_vp_decode(aloha_vp *vp, int space, uint64_t src_row, uint64_t limb_stride, double *host_re_im,
                              uint32_t nplain, uint32_t log_n, uint64_t modulus, double scale) {
   if (!vp || !host_re_im || !nplain || !(scale > 0)) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
   if (log_n < 10 || log_n > 16) return fail(vp, ALOHA_ERR_VL, "decode: log_n = %u", log_n);
   if (!modulus_ok(modulus)) return fail(vp, ALOHA_ERR_MODULUS, "decode: modulus = %#llx", (u64)modulus);
   const size_t N = (size_t)1 << log_n, n = N / 2;
@@ -1365,6 +1458,7 @@ aloha_status aloha_vp_get_stats(const aloha_vp *vp, aloha_vp_stats *out) {
 
 aloha_status aloha_vp_peek_vreg(aloha_vp *vp, uint32_t reg, uint64_t *dst, uint64_t n) {
   if (!vp || !dst || reg >= ALOHA_NVREG || n > (1ull << vp->max_logn)) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
   HIPCK(vp, hipMemcpyAsync(dst, vreg(vp, reg), n * 8, hipMemcpyDeviceToHost, vp->stream));
   HIPCK(vp, hipStreamSynchronize(vp->stream));
   return ALOHA_OK;

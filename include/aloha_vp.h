@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define ALOHA_VP_ABI_VERSION 1
+#define ALOHA_VP_ABI_VERSION 2
 
 typedef enum {
   ALOHA_OK = 0,
@@ -77,7 +77,8 @@ typedef struct {
 
 #define ALOHA_FLAG_NO_FUSION 1u    /* one kernel per instruction (debug / parity bisecting)  */
 #define ALOHA_FLAG_RADIX2_ONLY 2u /* transforms by radix-2 stage launches only (cross-check) */
-#define ALOHA_FLAG_NTT_TWO_PASS 4u  /* N = 2^12, 2^13 through the two-pass tile kernels too (default: single pass) */
+#define ALOHA_FLAG_NTT_TWO_PASS 4u  /* N = 2^12, 2^13 through the two-pass tile kernels too (default: single pass); N = 2^16
+                                       forward batches never as one fused launch (ALOHA_NTT_FUSED, off by default) */
 #define ALOHA_FLAG_NTT_SINGLE_14 8u /* N = 2^14 through the single-pass kernel as well (default: two passes)        */
 
 /* ---- lifecycle ----------------------------------------------------------------------- */
@@ -144,6 +145,7 @@ typedef struct {
   uint64_t instructions;    /* instructions retired since create                             */
   uint64_t kernel_launches; /* HIP kernel launches issued                                    */
   uint64_t twiddle_builds;  /* (q, N) twiddle tables generated                               */
+  uint64_t fused_launches;  /* of kernel_launches: N = 2^16 forward transforms run as ONE launch (ABI 2) */
 } aloha_vp_stats;
 aloha_status aloha_vp_get_stats(const aloha_vp *vp, aloha_vp_stats *out);
 /* copy a vector register to the host (debug; not architecturally visible in the reference) */

@@ -36,7 +36,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.aloha_vp_abi_version() == 1
+    assert lib.aloha_vp_abi_version() == 2
     for s in range(12):
         assert lib.aloha_status_string(s)
     assert lib.aloha_status_string(0) == b"ok"
@@ -55,7 +55,7 @@ def test_create_rejects_bad_config(lib):
     h = ctypes.c_void_p()
     cfg = avp._Config(abi_version=99, device=0, spm_rows=1, ksk_rows=1, max_log_n=13, flags=0, stream=None)
     assert lib.aloha_vp_create(ctypes.byref(cfg), ctypes.byref(h)) == avp.ERR_ARG
-    cfg = avp._Config(abi_version=1, device=0, spm_rows=1, ksk_rows=1, max_log_n=17, flags=0, stream=None)
+    cfg = avp._Config(abi_version=2, device=0, spm_rows=1, ksk_rows=1, max_log_n=17, flags=0, stream=None)
     assert lib.aloha_vp_create(ctypes.byref(cfg), ctypes.byref(h)) == avp.ERR_ARG
     assert lib.aloha_vp_create(None, ctypes.byref(h)) == avp.ERR_ARG
 
