@@ -282,6 +282,65 @@ inline uint32_t grid_for(uint32_t work_items) {
   return g > 2048 ? 2048 : (g ? g : 1);
 }
 
+
+// ---- measurement helpers: synthetic inputs and the VALU clock ------------------------------------
+// Synthetic residues of one limb: the accepted candidates, in order, of the splitmix64 stream seeded with
+// seed = seed_base + limb index -- output n (0-based) is mix(seed + (n + 1) * 0x9E3779B97F4A7C15), its top 60 bits
+// are the candidate, accepted when < q (rejection sampling: uniform in [0, q)).  splitmix64 is counter-based, so the
+// candidates are computed in parallel; a rejection shifts everything behind it, which a chunk detects with one
+// __syncthreads_count and repairs with a scan (for the largest 60-bit primes a rejection happens once in ~10^10).
+__device__ __forceinline__ u64 splitmix_out(u64 seed, u64 n) {
+  u64 z = seed + (n + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(1024) void fill_splitmix_kernel(u64 *__restrict__ base, const u64 *__restrict__ moduli,
+                                                             uint32_t n, u64 seed_base, u64 first_index) {
+  __shared__ uint32_t wave_rej[16];
+  const uint32_t limb = blockIdx.x, t = threadIdx.x;
+  u64 *out = base + (size_t)limb * n;
+  const u64 q = moduli[limb], seed = seed_base + first_index + limb;
+  uint32_t rej_before = 0;                     // rejected candidates in earlier chunks (uniform)
+  for (u64 c0 = 0; c0 - rej_before < n && c0 < 64ull * n; c0 += 1024) {   // (the host admits acceptance rates >= 1/16; the cap makes the loop finite whatever it is given)
+    const u64 cand = splitmix_out(seed, c0 + t) >> 4;
+    const bool rej = cand >= q;
+    const uint32_t nrej = __syncthreads_count(rej);
+    uint32_t before = 0;                       // rejected candidates of this chunk in front of this thread
+    if (nrej) {
+      const u64 m = __builtin_amdgcn_ballot_w64(rej);
+      if ((t & 63) == 0) wave_rej[t >> 6] = (uint32_t)__popcll(m);
+      __syncthreads();
+      for (uint32_t w = 0; w < (t >> 6); w++) before += wave_rej[w];
+      before += (uint32_t)__popcll(m & ((1ull << (t & 63)) - 1));
+      __syncthreads();
+    }
+    const u64 idx = c0 + t - rej_before - before;
+    if (!rej && idx < n) out[idx] = cand;
+    rej_before += nrej;
+  }
+}
+
+// VALU clock under an integer-multiply load: every SIMD hosts 8 waves, each issuing `iters` x 32 independent
+// v_mad_u64_u32 (8 chains of 4); at 8 waves per SIMD the pipeline is full, and one wave64 VALU instruction occupies a
+// 16-lane SIMD for 4 cycles (tools/ubench_valu.hip), so cycles per SIMD = 8 * 32 * iters * 4.
+__global__ __launch_bounds__(256) void valu_clock_kernel(u64 *sink, uint32_t iters) {
+  u64 a[8];
+  const uint32_t x = threadIdx.x * 2654435761u + blockIdx.x, y = x ^ 0x9e3779b9u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) a[i] = x + i;
+  for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) a[i] = mad32(lo32(a[i]), y, a[i]);
+  }
+  u64 s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s ^= a[i];
+  if (s == 0x123456789abcdefull) sink[0] = s;      // never true in practice: keeps the chains alive
+}
+
 }  // namespace
 
 hipError_t ew(hipStream_t st, EwOp op, u64 *d, const u64 *a, const u64 *b, u64 s, u64 sp, ModCtx m,
@@ -370,6 +429,19 @@ hipError_t vautn(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 kk)
 hipError_t vroli(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 s) {
   const uint32_t n = 1u << logn;
   hipLaunchKernelGGL(vroli_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, in, n, (uint32_t)s);
+  return hipGetLastError();
+}
+
+hipError_t fill_splitmix(hipStream_t st, u64 *base, const u64 *d_moduli, uint32_t count, uint32_t n, u64 seed_base,
+                         u64 first_index) {
+  if (!count) return hipSuccess;
+  hipLaunchKernelGGL(fill_splitmix_kernel, dim3(count), dim3(1024), 0, st, base, d_moduli, n, seed_base, first_index);
+  return hipGetLastError();
+}
+
+hipError_t valu_clock(hipStream_t st, u64 *d_sink, uint32_t simds, uint32_t iters) {
+  // 8 workgroups of 4 waves per CU (4 SIMDs): 8 waves per SIMD
+  hipLaunchKernelGGL(valu_clock_kernel, dim3(simds / 4 * 8), dim3(256), 0, st, d_sink, iters);
   return hipGetLastError();
 }
 

@@ -170,6 +170,14 @@ hipError_t ntt_fused_fwd(hipStream_t st, const LimbJob *d_jobs, const LimbJob *d
 hipError_t ntt_single_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
                             unsigned logn, bool inverse, uint64_t *launches, bool scaled = false);
 
+// ---- measurement helpers (ew_kernels.hip) ---------------------------------------------------------------
+// limb i of `count` limbs of n words at base + i*n: the first n accepted candidates (top 60 bits, < moduli[i]) of the
+// splitmix64 stream seeded with seed_base + first_index + i
+hipError_t fill_splitmix(hipStream_t st, u64 *base, const u64 *d_moduli, uint32_t count, uint32_t n, u64 seed_base,
+                         u64 first_index);
+// one launch of the VALU clock calibration: 8 waves per SIMD, 32 * iters v_mad_u64_u32 per wave
+hipError_t valu_clock(hipStream_t st, u64 *d_sink, uint32_t simds, uint32_t iters);
+
 // ---- CKKS encoder block (src/encoder), FP64: see encode_kernels.hip --------------------------------
 struct EncodeTables {      // per ring size N = 2^logn, n = N/2 slots; built by the host (vp_engine.cpp)
   const double *w;         // [n/2][2]  exp(-2*pi*i*k/n)

@@ -1328,6 +1328,60 @@ aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64
   return run_transforms(vp, jobs, log_n, inverse != 0);
 }
 
+
+/* Synthetic residues straight into HBM: limb i of `count` limbs at row + i*(N/128) receives the first N
+ * accepted 60-bit candidates of splitmix64(seed_base + first_index + i), accepted when < moduli[i]. */
+aloha_status aloha_vp_fill_synthetic(aloha_vp *vp, int space, uint64_t row, uint32_t log_n, const uint64_t *moduli,
+                                     uint32_t count, uint64_t seed_base, uint64_t first_index) {
+  if (!vp || !moduli) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
+  if (log_n < 10 || log_n > 16) return fail(vp, ALOHA_ERR_VL, "fill_synthetic: log_n = %u", log_n);
+  const uint64_t bytes = (uint64_t)count * ((1ull << log_n) / kLanes) * ALOHA_ROW_BYTES;
+  u64 *dst = space_ptr(vp, space, row, bytes);
+  if (!dst) return fail(vp, ALOHA_ERR_ADDR, "fill_synthetic: %u limbs at row %llu outside space %d", count, (u64)row, space);
+  for (uint32_t i = 0; i < count; i++)
+    if (moduli[i] < (1ull << 56) || moduli[i] > (1ull << 60))    // (an acceptance rate below 1/16 would make the rejection loop long)
+      return fail(vp, ALOHA_ERR_MODULUS, "fill_synthetic: modulus[%u] = %#llx is outside [2^56, 2^60]", i, (u64)moduli[i]);
+  if (!count) return ALOHA_OK;
+  const void *d_mod = nullptr;
+  aloha_status s = device_blob(vp, moduli, (size_t)count * 8, &d_mod);
+  if (s) return s;
+  HIPCK(vp, aloha::k::fill_splitmix(vp->stream, dst, (const u64 *)d_mod, count, 1u << log_n, seed_base, first_index));
+  vp->stats.kernel_launches++;
+  return ALOHA_OK;
+}
+
+/* Effective VALU clock (GHz) under an integer multiply-add load, measured now on this device: the figure that prices
+ * the transforms' instruction count (bench.py: roofline.valu).  Runs the calibration kernel for about `ms` milliseconds
+ * (clocks settle under load) and times its last launches. */
+aloha_status aloha_vp_valu_clock(aloha_vp *vp, double ms, double *ghz) {
+  if (!vp || !ghz || !(ms > 0)) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
+  hipDeviceProp_t prop;
+  HIPCK(vp, hipGetDeviceProperties(&prop, vp->device));
+  const uint32_t simds = (uint32_t)prop.multiProcessorCount * 4, iters = 4096;
+  hipEvent_t e0, e1;
+  HIPCK(vp, hipEventCreate(&e0));
+  HIPCK(vp, hipEventCreate(&e1));
+  double best_ms = 0;
+  float total = 0;
+  for (int rep = 0; rep < 1000 && total < ms; rep++) {
+    HIPCK(vp, hipEventRecord(e0, vp->stream));
+    for (int k = 0; k < 4; k++) HIPCK(vp, aloha::k::valu_clock(vp->stream, vp->d_scratch, simds, iters));
+    HIPCK(vp, hipEventRecord(e1, vp->stream));
+    HIPCK(vp, hipEventSynchronize(e1));
+    float t = 0;
+    HIPCK(vp, hipEventElapsedTime(&t, e0, e1));
+    total += t;
+    best_ms = t / 4;                                     // the LAST block: the settled clock
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const double cycles = 8.0 * 32.0 * iters * 4.0;        // per SIMD and launch (see valu_clock_kernel)
+  *ghz = cycles / (best_ms * 1e-3) / 1e9;
+  return ALOHA_OK;
+}
+
 }  // extern "C" (closed for two file-local helpers)
 
 // Tables of the encoder block for ring size N = 2^log_n (n = N/2): w[k] = exp(-2 pi i k / n),

@@ -281,12 +281,16 @@ class Exchange:
         self.always = always          # run the collectives even for world == 1 (single-rank NCCL smoke test)
         self.stream = stream
         self.stub = stub
+        self.bytes_sent = 0           # payload this rank has put on / taken off the links so far (accounting only)
+        self.bytes_received = 0
 
     def all_gather(self, vp, row0: int, chunk: int, world: int, rank: int) -> None:
         """All-gather of ``world`` chunks of ``chunk`` words laid out back to back from SPM row ``row0``
         (rank r owns chunk r)."""
         if (world == 1 and not self.always) or self.stub:
             return
+        self.bytes_sent += (world - 1) * chunk * 8
+        self.bytes_received += (world - 1) * chunk * 8
         import torch
         import torch.distributed as dist
         rows = chunk // LANES
@@ -338,6 +342,10 @@ class Exchange:
         import torch.distributed as dist
         src = owner(lo.L, lo.world)
         row = lo.row(lo.t)
+        if lo.rank == src:
+            self.bytes_sent += (lo.world - 1) * 2 * lo.n * 8
+        else:
+            self.bytes_received += 2 * lo.n * 8
         if self.tensor_of is not None and self.stream is not None:
             with torch.cuda.stream(self.stream):
                 dist.broadcast(self.tensor_of(vp, row, 2 * lo.n),

@@ -37,7 +37,8 @@ EXPORTS = ["aloha_vp_abi_version", "aloha_status_string", "aloha_vp_create", "al
            "aloha_vp_last_error", "aloha_vp_write", "aloha_vp_read", "aloha_vp_device_ptr",
            "aloha_vp_load_isram", "aloha_vp_load_isram_hex", "aloha_vp_run", "aloha_vp_sync",
            "aloha_vp_ntt_rows", "aloha_find_psi", "aloha_nth_prime", "aloha_vp_get_stats",
-           "aloha_vp_peek_vreg", "aloha_vp_encode", "aloha_vp_decode"]
+           "aloha_vp_peek_vreg", "aloha_vp_encode", "aloha_vp_decode", "aloha_vp_fill_synthetic",
+           "aloha_vp_valu_clock"]
 
 
 class AlohaError(RuntimeError):
@@ -95,6 +96,8 @@ def load_library() -> C.CDLL:
     L.aloha_vp_peek_vreg.restype = i; L.aloha_vp_peek_vreg.argtypes = [p, u32, p, u64]
     L.aloha_vp_encode.restype = i; L.aloha_vp_encode.argtypes = [p, i, u64, p, u32, u32, p, u32, C.c_double]
     L.aloha_vp_decode.restype = i; L.aloha_vp_decode.argtypes = [p, i, u64, u64, p, u32, u32, u64, C.c_double]
+    L.aloha_vp_fill_synthetic.restype = i; L.aloha_vp_fill_synthetic.argtypes = [p, i, u64, u32, p, u32, u64, u64]
+    L.aloha_vp_valu_clock.restype = i; L.aloha_vp_valu_clock.argtypes = [p, C.c_double, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -209,6 +212,19 @@ class VP:
         self._chk(self._L.aloha_vp_decode(self._h, space, src_row, limb_stride, out.ctypes.data, nplain, log_n,
                                           modulus, float(scale)))
         return out
+
+    # -- measurement helpers ---------------------------------------------------------------------
+    def fill_synthetic(self, space: int, row: int, log_n: int, moduli: Sequence[int], seed_base: int = 0xA10A,
+                       first_index: int = 0) -> None:
+        """Limb i at row + i*(N/128): uniform residues below moduli[i] from splitmix64(seed_base + first_index + i)
+        (SURVEY 8d), generated on the device."""
+        m = np.ascontiguousarray(moduli, dtype=np.uint64)
+        self._chk(self._L.aloha_vp_fill_synthetic(self._h, space, row, log_n, m.ctypes.data, len(m), seed_base, first_index))
+
+    def valu_clock_ghz(self, ms: float = 60.0) -> float:
+        out = C.c_double()
+        self._chk(self._L.aloha_vp_valu_clock(self._h, float(ms), C.byref(out)))
+        return float(out.value)
 
     # -- introspection ------------------------------------------------------------------------
     def stats(self) -> dict:

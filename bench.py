@@ -3,6 +3,11 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--primes L] [--polys P]
 
+With --gpus N > 1 and no launcher (WORLD_SIZE unset) the script starts its N ranks itself, one per GPU, before it
+touches the GPU; under torch.distributed.run it uses the ranks it is given.  After W warm-up steps an untimed settle
+loop runs until the step time is stable (`settle_ms` in the output: the clocks of a freshly loaded GPU need ~100 ms),
+then exactly K steps are timed.  For N > 1 a second object `keyswitch` reports BASELINE config 4 sharded over the ranks.
+
 One "step" = one pass of the hot path (vntt, fused over the batch: aloha_vp_ntt_rows) over a
 batch of L x P limbs of N = 2^16 coefficients resident in HBM, in place.  The default batch
 (32 primes x 128 limbs = 4096 limbs = 2 GiB) is eight times the 256 MiB Infinity Cache, so every
@@ -36,20 +41,55 @@ import torch  # noqa: E402
 LOGN = 16
 N = 1 << LOGN
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = "r01_s_pmc_summary.json"   # written by tools/collect_pmc.sh for the kernels of this commit
+PMC_SUMMARY = "r02_pmc_summary.json"     # written by tools/collect_pmc.sh; its "commit" field says for which kernels
+
+
+def pmc_summary():
+    """The committed rocprofv3 PMC summary of this same command (separate --pmc passes, tools/collect_pmc.sh), or {}."""
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_SUMMARY)) as f:
+            return json.load(f)
+    except Exception:
+        return {}
 
 
 def measured_traffic_per_step(limbs: int):
-    """HBM bytes per step from the committed rocprofv3 PMC summary (FETCH_SIZE x2 per the guide's
-    gfx950 correction + WRITE_SIZE, separate --pmc passes of this same command), scaled to the
-    batch size; None when no summary is present."""
-    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+    """HBM bytes per step from the PMC summary (FETCH_SIZE x2 per the guide's gfx950 correction + WRITE_SIZE), scaled
+    to the batch size; None when no summary is present."""
     try:
-        with open(path) as f:
-            d = json.load(f)["derived"]
+        d = pmc_summary()["derived"]
         return d["hbm_bytes_per_step_corrected"] * limbs / (d["algorithmic_bytes_per_step"] / (16 * N))
     except Exception:
         return None
+
+
+def valu_insts_per_ntt():
+    """VALU lane-instructions per transform from the PMC summary: SQ_INSTS_VALU counts wave64 instructions per launch
+    of the 4096-limb batch, both kernels; None when no summary is present."""
+    try:
+        d = pmc_summary()
+        waves = d["ntt_col_kernel.SQ_INSTS_VALU"] + d["ntt_row_kernel.SQ_INSTS_VALU"]
+        return waves * 64.0 / (d["derived"]["algorithmic_bytes_per_step"] / (16 * N))
+    except Exception:
+        return None
+
+
+def self_launch(argv, gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same script, one per GPU, BEFORE anything in
+    this process touches the GPU (the parent only waits), and return the worst exit code.  The driver's own launcher
+    (torch.distributed.run) sets WORLD_SIZE, in which case this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    return max(p.wait() for p in procs)
+
 
 
 def cpu_baseline(seconds: float = 8.0, check=None) -> dict:
@@ -98,6 +138,96 @@ def cpu_baseline(seconds: float = 8.0, check=None) -> dict:
                                       "cycles_per_ntt_n8192": 850, "ntt_per_s_n8192": 1e8 / 850}}
 
 
+def settle(step, sync, min_ms: float = 120.0, max_ms: float = 1500.0, block_ms: float = 20.0, tol: float = 0.01):
+    """Untimed steps until the step time is stable: the clocks of a freshly loaded MI355X dip ~25 % for the first
+    milliseconds of sustained launches and take ~100 ms to settle, and the driver's short runs
+    (--steps 20) would otherwise time that transient.  Runs blocks of ~block_ms, stops once at least min_ms have
+    passed and two consecutive blocks agree within tol (or at max_ms).  Returns (ms spent, steps run)."""
+    t_start = time.perf_counter()
+    step(); sync()
+    t0 = time.perf_counter(); step(); sync()
+    one = max(1e-5, time.perf_counter() - t0)
+    k = max(1, int(block_ms / 1e3 / one))
+    prev, total = None, 2
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        sync()
+        cur = (time.perf_counter() - t0) / k
+        total += k
+        spent = (time.perf_counter() - t_start) * 1e3
+        if (spent >= min_ms and prev is not None and abs(cur - prev) <= tol * prev) or spent >= max_ms:
+            return spent, total
+        prev = cur
+
+
+def keyswitch_leg(dist, backend, rank, world, local_rank):
+    """BASELINE config 4 on the ranks of this run: HMult + relinearisation at N = 2^16, L = 24, hybrid key-switch
+    with alpha = K = 4 (aloha_amd/hybrid.py), RNS limbs sharded limb j -> rank j mod world, the digit all-gather and
+    the mod-down all-gather over torch.distributed (keyswitch.mem:4-43,:80-83 are the steps they parallelise).  Timed
+    with the collective and with world-1 direct sends per rank; every rank checks its owned output limbs against a
+    single-rank engine running the same operation on the same inputs."""
+    from aloha_amd import hybrid, keyswitch
+    from aloha_amd import vp as avp
+    L, alpha, reps = 24, 4, 10
+    mods = [avp.nth_prime(LOGN, i) for i in range(L)]
+    specials = [avp.nth_prime(LOGN, L + k) for k in range(alpha)]
+    on_gpu = backend == "nccl"
+
+    def load(ks, lo):
+        for jl, j in enumerate(lo.owned_all):                   # key and ciphertext words depend on the limb only
+            kl = np.random.default_rng(7000 + j).integers(0, (mods + specials)[j], lo.dnum * 2 * N, dtype=np.uint64)
+            ks.vp.write(1, (jl * lo.dnum) * 2 * lo.rows, kl)
+        ct = np.stack([np.random.default_rng(539 + j).integers(0, mods[j % L], N, dtype=np.uint64) for j in range(2 * L)])
+        ks.load_ct(ct); ks.load_ct_b(ct[::-1].copy())
+
+    res = {"config": f"HMult + relinearisation, N=2^16, L={L} (+{alpha} special), hybrid key-switch alpha={alpha}, limbs sharded j -> rank j mod {world}",
+           "n_gpus": world, "reps": reps, "backend": backend}
+    t_of = lambda *a: torch.tensor(list(a), dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+    out = None
+    for mode in ("collective", "p2p"):
+        stream = torch.cuda.Stream()
+        lo = hybrid.HybridLayout(N, mods, specials, alpha, world, rank)
+        ex = keyswitch.Exchange(tensor_of=keyswitch.device_tensor if on_gpu else None, stream=stream if on_gpu else None,
+                                p2p=(mode == "p2p"))
+        with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=max(1, lo.ksk_limbs * lo.rows), max_log_n=LOGN, device=local_rank,
+                    stream=stream.cuda_stream) as vp:
+            ks = hybrid.HybridKeySwitch(vp, N, mods, specials, alpha, world=world, rank=rank, exchange=ex)
+            load(ks, lo)
+            ks.multiply(); vp.sync()
+            dist.barrier(); torch.cuda.synchronize()
+            sent0, recv0 = ex.bytes_sent, ex.bytes_received
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ks.multiply()
+            vp.sync()
+            el = time.perf_counter() - t0
+            t = t_of(el); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res[f"ms_{mode}"] = float(t[0]) / reps * 1e3
+            res[f"bytes_sent_per_rank_{mode}"] = (ex.bytes_sent - sent0) // reps
+            res[f"bytes_received_per_rank_{mode}"] = (ex.bytes_received - recv0) // reps
+            if out is None:
+                out = ks.read_out()
+                owned = list(lo.owned_ct)
+            else:                                                # both exchange forms must give the same words
+                same = bool(np.array_equal(out, ks.read_out()))
+                t = t_of(1.0 if same else 0.0); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                res["p2p_equals_collective"] = bool(t[0] > 0.5)
+    lo1 = hybrid.HybridLayout(N, mods, specials, alpha, 1, 0)
+    with avp.VP(spm_rows=lo1.spm_rows_needed, ksk_rows=lo1.ksk_limbs * lo1.rows, max_log_n=LOGN, device=local_rank) as vp1:
+        ks1 = hybrid.HybridKeySwitch(vp1, N, mods, specials, alpha, world=1, rank=0, exchange=keyswitch.Exchange())
+        load(ks1, lo1)
+        ks1.multiply()
+        ref = ks1.read_out()
+    ok = all(np.array_equal(out[:, i], ref[:, j]) for i, j in enumerate(owned))
+    t = t_of(1.0 if ok else 0.0); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    res["verified"] = bool(t[0] > 0.5)
+    res["ms"] = min(res["ms_collective"], res["ms_p2p"])
+    res["exchange"] = "p2p" if res["ms_p2p"] < res["ms_collective"] else "collective"
+    return res
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,14 +236,21 @@ def main() -> int:
     ap.add_argument("--primes", type=int, default=32)
     ap.add_argument("--polys", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle loop (A/B: shows the clock transient)")
+    ap.add_argument("--no-keyswitch", action="store_true", help="N > 1 only: skip the sharded key-switch leg")
     ap.add_argument("--inverse", action="store_true", help="time vintt instead (side metric; headline is forward)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(sys.argv[1:], args.gpus)             # nothing above has touched the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
+    if world != args.gpus:
+        print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; the group size is what is reported", file=sys.stderr)
+    if os.environ.get("ALOHA_BENCH_ECHO"):                       # (tests: shows what a rank was started with)
+        print(f"bench.py rank {rank} of {world} local {local_rank} master {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+              file=sys.stderr)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the engine has no CPU path", file=sys.stderr)
         return 2
@@ -130,6 +267,7 @@ def main() -> int:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        world = dist.get_world_size()                            # n_gpus in the JSON line is the group's size
 
     from aloha_amd import vp as avp
 
@@ -141,16 +279,10 @@ def main() -> int:
                 stream=stream.cuda_stream)
     primes = [avp.nth_prime(LOGN, i) for i in range(L)]
     moduli = [q for q in primes for _ in range(P)]
-    # synthetic canonical residues, uniform in [0, q), generated on the device straight into the
-    # engine's memory (a zero-copy int64 view), prime by prime
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(0xA10A + rank)
-    for i, q in enumerate(primes):
-        class _View:
-            __cuda_array_interface__ = {"shape": (P * N,), "typestr": "<i8", "version": 2,
-                                        "data": (vp.device_ptr(avp.SPM, i * P * rows_per_limb), False)}
-        torch.as_tensor(_View(), device="cuda").random_(0, q, generator=gen)
-    torch.cuda.synchronize()
+    # synthetic inputs: the L largest primes p < 2^60, p = 1 mod 2N; limb i = canonical residues uniform in
+    # [0, p) from splitmix64(0xA10A + global limb index) with rejection, generated on the device
+    vp.fill_synthetic(avp.SPM, 0, LOGN, moduli, seed_base=0xA10A, first_index=rank * B)
+    vp.sync()
     first_in = vp.read(avp.SPM, 0, N)
     assert int(first_in.max()) < primes[0]
     # correctness guards inside the bench: the first limb of the first step is kept for the CPU leg
@@ -168,9 +300,11 @@ def main() -> int:
             print("bench.py: NTT round trip failed on the last limb", file=sys.stderr)
             return 3
     inv = bool(args.inverse)
+    step = lambda: vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli, inverse=inv)
     for _ in range(max(0, args.warmup - 1)):
-        vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli, inverse=inv)
+        step()
     vp.sync()
+    settle_ms, settle_steps = (0.0, 0) if args.no_settle else settle(step, vp.sync)
     launches0 = vp.stats()["kernel_launches"]
 
     def barrier():
@@ -184,7 +318,7 @@ def main() -> int:
     with torch.cuda.stream(stream):
         ev0.record(stream)
         for _ in range(args.steps):
-            vp.ntt_rows(avp.SPM, 0, 0, LOGN, moduli, inverse=inv)
+            step()
         ev1.record(stream)
     vp.sync()
     torch.cuda.synchronize()
@@ -196,28 +330,54 @@ def main() -> int:
         t = torch.tensor([elapsed, dev_ms], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
+    clock_ghz = vp.valu_clock_ghz(60.0) if rank == 0 else None   # right behind the timed region: the same thermal state
+    vp.close()
+
+    ks = None
+    if dist is not None and world > 1 and not args.no_keyswitch:
+        ks = keyswitch_leg(dist, backend, rank, world, local_rank)
 
     if rank == 0:
         total_ntts = world * B * args.steps
         alg_bytes_step = 16 * N * B                         # read N + write N words per transform
         dev_s_step = dev_ms / 1e3 / args.steps
         achieved = alg_bytes_step / dev_s_step / 1e9
+        hbm_bound_ntt_s = HBM_PEAK_GBS * 1e9 / (16 * N)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_per_step(B),
+                "note": "achieved = 16*N*B algorithmic bytes / device time of one step (both tile kernels, HIP events on "
+                        f"the engine's stream); traffic = HBM bytes per step from profiles/{PMC_SUMMARY} (rocprofv3 --pmc, "
+                        "FETCH_SIZE x2 + WRITE_SIZE; two passes + twiddle blocks => ~2.04x algorithmic; its `commit` field names "
+                        "the kernels it was collected on); valu = the second bound (SURVEY 8d): lane-instructions per transform "
+                        "(SQ_INSTS_VALU of the same summary) against 16 lanes x SIMDs x the VALU clock measured by a multiply-add "
+                        "calibration kernel right after the timed region; `bound` names the tighter of the two"}
+        insts = valu_insts_per_ntt()
+        if insts and clock_ghz:
+            simds = 1024                                     # 256 CUs x 4 SIMDs of 16 lanes (MI355X_MICROARCH.md)
+            valu_bound = 16.0 * simds * clock_ghz * 1e9 / insts
+            roof["valu"] = {"insts_per_ntt": insts, "insts_per_butterfly": insts / (N // 2 * LOGN), "clock_ghz": clock_ghz,
+                            "bound_ntt_per_s": valu_bound, "frac_of_valu_bound": (B / dev_s_step) / valu_bound,
+                            "as_frac_of_hbm_roofline": valu_bound / hbm_bound_ntt_s}
+            roof["hbm_bound_ntt_per_s"] = hbm_bound_ntt_s
+            if valu_bound < hbm_bound_ntt_s:
+                roof["bound"] = "valu"
+        pm = pmc_summary()
+        if pm.get("commit"):
+            roof["traffic_commit"] = pm["commit"]
         out = {
             "metric": ("inv-NTT/s" if inv else "fwd-NTT/s") + " at N=2^16, 60-bit prime", "value": total_ntts / elapsed, "unit": "NTT/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "settle_ms": settle_ms, "settle_steps": settle_steps,
             "config": {"workload": f"{'inverse negacyclic NTT (vintt)' if inv else 'forward negacyclic NTT (vntt)'}, N=2^16, batch of {B} limbs per GPU "
-                                   f"({L} 60-bit primes x {P} limbs), in place in HBM ({B * N * 8 >> 20} MiB)",
+                                   f"({L} 60-bit primes x {P} limbs), in place in HBM ({B * N * 8 >> 20} MiB); inputs: splitmix64(0xA10A + limb) residues",
                        "log_n": LOGN, "limbs_per_gpu": B, "primes": L, "limbs_per_prime": P,
                        "kernels_per_step": launches // max(1, args.steps)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_per_step(B),
-                         "note": "achieved = 16*N*B algorithmic bytes / device time of one step (both "
-                                 "tile kernels, HIP events on the engine's stream); traffic = HBM bytes "
-                                 f"per step from profiles/{PMC_SUMMARY} (rocprofv3 --pmc, FETCH_SIZE x2 + "
-                                 "WRITE_SIZE; two passes + twiddle blocks => ~2.04x algorithmic); see DESIGN.md"},
+            "roofline": roof,
         }
+        if ks is not None:
+            out["keyswitch"] = ks
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(check=(first_in, primes[0], first_out))
             if out["cpu_baseline"]["gpu_first_limb_equals_cpu"] is False and not os.environ.get("ALOHA_VP_LIB"):
@@ -226,7 +386,6 @@ def main() -> int:
         alg_tw = alg_bytes_step + 2 * 8 * N * L             # + one twiddle table and its Shoup companion per prime
         out["roofline"]["achieved_twiddle_inclusive"] = alg_tw / dev_s_step / 1e9
         print(json.dumps(out))
-    vp.close()
     if dist is not None:
         dist.destroy_process_group()
     return 0

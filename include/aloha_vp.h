@@ -133,6 +133,16 @@ aloha_status aloha_vp_encode(aloha_vp *vp, int space, uint64_t dst_row, const do
 aloha_status aloha_vp_decode(aloha_vp *vp, int space, uint64_t src_row, uint64_t limb_stride, double *host_re_im,
                              uint32_t nplain, uint32_t log_n, uint64_t modulus, double scale);
 
+/* ---- measurement helpers (no counterpart in the reference) -------------------------------------
+ * Synthetic inputs generated in HBM: limb i of `count` limbs of N = 2^log_n words at row + i*(N/128) receives the
+ * first N accepted candidates of the splitmix64 stream seeded with seed_base + first_index + i, where a candidate is
+ * the top 60 bits of an output and is accepted when < moduli[i] (uniform canonical residues; 2^56 <= modulus <= 2^60). */
+aloha_status aloha_vp_fill_synthetic(aloha_vp *vp, int space, uint64_t row, uint32_t log_n, const uint64_t *moduli,
+                                     uint32_t count, uint64_t seed_base, uint64_t first_index);
+/* Effective VALU clock in GHz under an integer multiply-add load, measured on the handle's device for about `ms`
+ * milliseconds: prices a kernel's VALU instruction count (the second bound next to HBM bandwidth). */
+aloha_status aloha_vp_valu_clock(aloha_vp *vp, double ms, double *ghz);
+
 /* ---- parameters ------------------------------------------------------------------------------ */
 /* minimal primitive 2N-th root of unity mod q -- the rule behind the reference's hard-coded
  * psi values (tf_rom_generator.sv:75) */

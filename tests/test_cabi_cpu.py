@@ -78,3 +78,25 @@ def test_host_parameter_helpers_match_oracle(lib):
     with pytest.raises(avp.AlohaError) as e:
         avp.find_psi(Q0 + 2, 13)
     assert e.value.status == avp.ERR_MODULUS
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with WORLD_SIZE unset starts N ranks itself (the first driver SCALE run would otherwise
+    time one rank and print n_gpus: 1).  On this CPU-only host every rank stops at its GPU check, after saying what it
+    was started with."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ALOHA_BENCH_ECHO"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the ranks would run the benchmark")
+    assert p.returncode == 2, p.stderr
+    lines = [l for l in p.stderr.splitlines() if l.startswith("bench.py rank ")]
+    assert sorted(l.split()[2] for l in lines) == ["0", "1", "2"]
+    assert all(" of 3 " in l and "master 127.0.0.1:" in l for l in lines)
+    assert len({l.split("master ")[1] for l in lines}) == 1          # one rendezvous for all ranks
+    assert p.stderr.count("bench.py needs a GPU") == 3

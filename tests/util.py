@@ -73,6 +73,25 @@ def splitmix64(seed: int, count: int) -> np.ndarray:
     return out
 
 
+def splitmix_residues(seed: int, n: int, q: int) -> np.ndarray:
+    """The first n accepted candidates of splitmix64(seed): candidate = top 60 bits of an output, accepted when < q
+    (SURVEY 8d's synthetic inputs; the rule aloha_vp_fill_synthetic implements on the device)."""
+    out = np.empty(0, dtype=np.uint64)
+    start = 0
+    with np.errstate(over="ignore"):
+        while out.size < n:
+            m = max(1024, 2 * (n - out.size))
+            idx = np.arange(start + 1, start + m + 1, dtype=np.uint64)
+            z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            c = z >> np.uint64(4)
+            out = np.concatenate([out, c[c < np.uint64(q)]])
+            start += m
+    return out[:n]
+
+
 def random_residues(rng: np.random.Generator, shape, q: int) -> np.ndarray:
     """Uniform canonical residues in [0, q)."""
     a = rng.integers(0, q, size=shape, dtype=np.uint64)

@@ -39,7 +39,8 @@ def main() -> int:
         if g == full[k]:
             acc[k][c].append(v)
     out = {"note": "rocprofv3 --pmc, one counter group per run, bench.py --steps 3 --warmup 2 "
-                   f"({LIMBS} limbs, N=2^16); averages per launch"}
+                   f"({LIMBS} limbs, N=2^16); averages per launch",
+           "commit": os.environ.get("ALOHA_COMMIT", "")}      # the tree the counters were collected on (tools/collect_pmc.sh)
     for k, cs in sorted(acc.items()):
         for c, vals in sorted(cs.items()):
             out[f"{k}.{c}"] = sum(vals) / len(vals)
