@@ -123,11 +123,38 @@ struct aloha_vp {
     uint32_t pc = 0;
     uint64_t epoch = 0, instructions = 0;
     std::vector<std::function<hipError_t()>> ops;
+    // ALOHA_RUN_GRAPH=1 (experiment, off): from its second replay on a list becomes a hipGraph -- the launches captured once
+    // from `ops` on the handle's stream, re-issued by ONE hipGraphLaunch.  Measured on ROCm 7.2 / MI355X it is SLOWER for
+    // these 4-7 kernel graphs: ~50 us of host time per hipGraphLaunch against ~3 us per plain launch (rank 0's share of a
+    // sharded key-switch 0.43 ms instead of 0.11 ms, profiles/r02_l_ks_probe_*.jsonl), so the launch list stays the default.
+    // A list that cannot be captured stays a list.
+    hipGraphExec_t graph = nullptr;
+    bool graph_failed = false;
+    uint32_t replays = 0;
+    uint64_t launches = 0;                           // kernel launches per replay (statistics of a graph launch)
+    RunPlan() = default;
+    RunPlan(const RunPlan &) = delete;
+    RunPlan &operator=(const RunPlan &) = delete;
+    RunPlan(RunPlan &&o) noexcept { *this = std::move(o); }
+    RunPlan &operator=(RunPlan &&o) noexcept {
+      if (this != &o) {
+        if (graph) (void)hipGraphExecDestroy(graph);
+        inst = std::move(o.inst); imm = std::move(o.imm); ops = std::move(o.ops);
+        memcpy(csr, o.csr, sizeof csr);
+        step = o.step; vl_in = o.vl_in; q_in = o.q_in; mu_in = o.mu_in; vl_out = o.vl_out; q_out = o.q_out; mu_out = o.mu_out;
+        pc = o.pc; epoch = o.epoch; instructions = o.instructions;
+        graph = o.graph; graph_failed = o.graph_failed; replays = o.replays; launches = o.launches;
+        o.graph = nullptr;
+      }
+      return *this;
+    }
+    ~RunPlan() { if (graph) (void)hipGraphExecDestroy(graph); }
   };
   std::unordered_multimap<uint64_t, RunPlan> run_cache;
   RunPlan *rec = nullptr;                            // non-null while a run is being recorded
   uint64_t epoch = 0;                                // bumped whenever a cached device object a plan may point to is freed
   bool run_cache_on = true;
+  bool graphs_on = false;                            // ALOHA_RUN_GRAPH=1: replay recorded runs as hipGraphs (measured SLOWER on ROCm 7.2, off)
   aloha_vp_stats stats{};
   std::string err;
 };
@@ -430,6 +457,7 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   vp->max_logn = cfg->max_log_n;
   if (const char *e = getenv("ALOHA_NTT_CHUNK")) vp->chunk_limbs = (uint32_t)strtoul(e, nullptr, 10);
   vp->run_cache_on = !getenv("ALOHA_NO_RUN_CACHE");          // (A/B switch: every run goes through the sequencer again)
+  vp->graphs_on = getenv("ALOHA_RUN_GRAPH") != nullptr;
   // fused single-launch forward transform (N = 2^16), an experiment kept behind a switch: ALOHA_NTT_FUSED = the smallest
   // batch it serves (unset or 0: never);
   // ALOHA_NTT_FUSED_DELAY = limb groups between a column tile and the row tiles that read it;
@@ -677,15 +705,38 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       run_hash = h;
       auto range = vp->run_cache.equal_range(h);
       for (auto it = range.first; it != range.second; ++it) {
-        const aloha_vp::RunPlan &pl = it->second;
+        aloha_vp::RunPlan &pl = it->second;
         if (pl.epoch != vp->epoch || pl.pc != pc || pl.inst.size() != len || pl.step != step || pl.vl_in != vp->vl_bits ||
             pl.q_in != vp->q || pl.mu_in != vp->mu || memcmp(pl.csr, csr, sizeof csr) != 0 ||
             memcmp(pl.inst.data(), &vp->inst[pc], len * sizeof(uint32_t)) != 0 ||
             memcmp(pl.imm.data(), &vp->imm[pc], len * sizeof(uint64_t)) != 0)
           continue;
-        for (const auto &op : pl.ops) {
-          const hipError_t e = op();
-          if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "replayed launch failed: %s", hipGetErrorString(e));
+        if (vp->graphs_on && !pl.graph && !pl.graph_failed && ++pl.replays >= 2 && !vp->fused_stats) {
+          // capture the list once; a failure (an op that cannot be captured) leaves it a list for good
+          const uint64_t l0 = vp->stats.kernel_launches, f0 = vp->stats.fused_launches;
+          bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+          if (ok) {
+            for (const auto &op : pl.ops) ok = (op() == hipSuccess) && ok;
+            hipGraph_t g = nullptr;
+            ok = (hipStreamEndCapture(st, &g) == hipSuccess) && ok && g;
+            if (ok) ok = hipGraphInstantiate(&pl.graph, g, nullptr, nullptr, 0) == hipSuccess;
+            if (g) (void)hipGraphDestroy(g);
+          }
+          pl.launches = vp->stats.kernel_launches - l0;
+          vp->stats.kernel_launches = l0;                // nothing ran during the capture
+          vp->stats.fused_launches = f0;
+          if (!ok) { pl.graph = nullptr; pl.graph_failed = true; (void)hipGetLastError(); }
+        }
+        if (pl.graph) {
+          const hipError_t e = hipGraphLaunch(pl.graph, st);
+          if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "graph launch of a recorded run failed: %s", hipGetErrorString(e));
+          vp->stats.kernel_launches += pl.launches;
+          vp->stats.graph_launches++;
+        } else {
+          for (const auto &op : pl.ops) {
+            const hipError_t e = op();
+            if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "replayed launch failed: %s", hipGetErrorString(e));
+          }
         }
         vp->vl_bits = pl.vl_out; vp->q = pl.q_out; vp->mu = pl.mu_out;
         vp->stats.instructions += pl.instructions;

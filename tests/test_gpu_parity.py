@@ -656,6 +656,17 @@ def test_random_programs_fused_unfused_oracle(engine, seed):
             vp.sync()
             again.append(vp.read(SPM, 0, total))
         assert np.array_equal(again[0], again[1]), "replayed run vs oracle"
+        # ... and twice more (with ALOHA_RUN_GRAPH=1 the list is captured into a hipGraph on its second replay)
+        for rep in range(2):
+            mem3 = np.stack([residues(rng, n, primes[0]) for _ in range(nslots)])
+            third = []
+            for vp in (engine, o):
+                vp.write(SPM, 0, np.zeros(total, np.uint64))
+                vp.write(SPM, 0, mem3.reshape(-1))
+                assert vp.run(0, src0=0, step=2 * seed + 1) == 0
+                vp.sync()
+                third.append(vp.read(SPM, 0, total))
+            assert np.array_equal(third[0], third[1]), f"graph replay #{rep} vs oracle"
     finally:
         plain.close()
 

@@ -428,3 +428,35 @@ def test_replayed_phases_on_new_data_and_new_steps():
             for hs in (g, o):
                 hs.rescale()
             assert np.array_equal(g.read_out()[:, :L - 1], o.read_out()[:, :L - 1]), f"rescale #{i}"
+
+
+@pytest.mark.gpu
+def test_baseline_config5_rotation_batch_at_full_size_gpu_equals_oracle_machine():
+    """BASELINE config 5 is a BATCH of rotations: N = 2^16, L = 32 (+4 special), hybrid alpha = 4, three rotation
+    steps of one decomposed ciphertext in ONE pass of the phases (``hoist_one`` + ``rotate_hoisted_many``, each step
+    with its own key region): every output word of every rotation slot on the GPU == the oracle's ISA machine
+    running the same programs.  Reference step it widens: keyswitch.mem:4-121, run once per rotation."""
+    from aloha_amd import vp as avp
+    n, L, K, alpha, R = 1 << 16, 32, 4, 4, 3
+    mods, specials = _setup(n, L, K, 0)
+    lo = hybrid.HybridLayout(n, mods, specials, alpha, batch=R)
+    rng = np.random.default_rng(532)
+    ct = np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
+    steps = [pow(3, r + 1, 2 * n) for r in range(R)]
+
+    def run(vp):
+        hs = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha, batch=R)
+        for r in range(R):                                        # one key region per rotation; any words serve as a key
+            for jl, j in enumerate(lo.owned_all):
+                vp.write(keyswitch.KSK, r * hs.key_rows + jl * lo.dnum * 2 * lo.rows,
+                         np.random.default_rng(8000 + 100 * r + j).integers(0, lo.mods_all[j], lo.dnum * 2 * n, dtype=np.uint64))
+        hs.load_ct(ct)
+        hs.hoist_one()
+        hs.rotate_hoisted_many(steps)
+        return np.stack([hs.read_out(b) for b in range(R)])
+
+    exp = run(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=R * lo.ksk_limbs * lo.rows))
+    with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=R * lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
+        got = run(vp)
+    assert np.array_equal(got, exp)
+    assert not np.array_equal(got[0], got[1])                    # the slots really are different rotations
