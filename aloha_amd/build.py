@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libaloha_vp.so")
-SOURCES = ["vp_engine.cpp", "numtheory.cpp", "ew_kernels.hip", "ntt_tile.hip", "ntt_single.hip", "encode_kernels.hip"]
+SOURCES = ["vp_engine.cpp", "keyswitch_host.cpp", "numtheory.cpp", "ew_kernels.hip", "ntt_tile.hip", "ntt_single.hip", "encode_kernels.hip"]
 HEADERS = ["kernels.hpp", "modarith.hpp", "ntt_device.hpp", "numtheory.hpp", os.path.join("..", "..", "include", "aloha_vp.h")]
 ARCH = "gfx950"
 
@@ -39,7 +39,7 @@ def build_variant(name: str, defines) -> str:
     out = os.path.join(LIBDIR, f"libaloha_vp_{name}.so")
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}"] + [f"-D{d}" for d in defines] + \
-          ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl,-rpath,/opt/rocm/lib"]
+          ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl,-rpath,/opt/rocm/lib", "-ldl"]
     subprocess.check_call(cmd)
     return out
 
@@ -65,7 +65,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             subprocess.check_call(cmd)
             rebuilt = True
     if rebuilt or not os.path.exists(LIB):
-        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

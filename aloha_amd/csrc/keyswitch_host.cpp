@@ -1,0 +1,649 @@
+// keyswitch_host.cpp -- the L-limb key-switch of the VP as a C host (C ABI: aloha_ks_* in include/aloha_vp.h).
+//
+// The reference has ONE place where limbs interact: the rotate / key-switch micro-program
+// (sim/vp/isram_file_generator/keyswitch.mem:1-122; digits :4-43, inner products :46-79, mod-down :80-121), written for
+// L = 2 ciphertext primes and one special prime, driven by the test-bench task run_rotate
+// (sim/top/top_noaxilite_tb.sv:522-532).  This file is that program for any L, K special primes and alpha primes per
+// digit (alpha = 1, K = 1: the reference's algorithm step for step), generated as HE-ISA phase programs and run on an
+// aloha_vp handle, with the RNS limbs sharded over the ranks of one node -- limb j (ciphertext and special primes alike)
+// on rank j mod world -- and the two exchange steps issued straight on RCCL:
+//     phase 1        X = vautn(c1) | d2,  ROT = vautn(c0) | d0;  Y[i] = iNTT(X[i]) * (Q_d/q_i)^-1        per owned limb
+//     ncclAllGather  of the L coefficient-form digits Y                 (keyswitch.mem:4-5,:24-25 are what it spreads)
+//     phase 2        ModUp sums + NTT under every owned modulus; inner products with the key     (keyswitch.mem:9-14,:46-79)
+//     phase 3        owners of special primes: W = (iNTT(acc) + floor(P/2)) * (P/p_k)^-1          (keyswitch.mem:80-83)
+//     ncclAllGather  of the 2K mod-down terms W
+//     phase 4        t = NTT(sum_k W_k (P/p_k) - floor(P/2));  out = (acc - t) P^-1 + base        (keyswitch.mem:86-121)
+// The programs, slot layout and scalars are those of aloha_amd/hybrid.py (HybridLayout, blocks_*): tests/ compares the
+// two generators word for word, and the Python classes remain the driver of the oracle's ISA machine in the parity
+// tests.  RCCL is loaded with dlopen at first use (librccl.so.1, or the one a hosting process has already mapped), so
+// the library itself has no link-time dependency on it and a single-rank user never touches it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/aloha_vp.h"
+#include "numtheory.hpp"
+
+namespace {
+
+using aloha::nt::invmod;
+using aloha::nt::mulmod;
+typedef unsigned long long u64;
+
+constexpr uint32_t kOpcode = 0x0B, kDepth = ALOHA_IRAM_DEPTH;
+constexpr uint64_t kPtrAbs = 3, kPtrKsk = 15;     // pointer select in imm[63:48] (vp_top_full.sv:105-117; 3 = none = absolute)
+
+struct Ins { uint32_t inst; uint64_t imm; };
+typedef std::vector<Ins> Block;
+
+// encodings: expander.v:65-81,:123-130 (unused fields as the shipped programs encode them, cf. aloha_amd/isa.py)
+inline Ins enc(uint32_t f6, uint32_t vd, uint32_t vs1, uint32_t vs2, uint32_t f3, uint64_t imm) {
+  return Ins{(f6 << 26) | (1u << 25) | (vs2 << 20) | (vs1 << 15) | (f3 << 12) | (vd << 7) | kOpcode, imm};
+}
+inline Ins i_setvl(uint64_t bits) { return enc(0x04, 0, 0, 0, 2, bits); }
+inline Ins i_setq(uint64_t q) { return enc(0x08, 0, 0, 0, 2, q); }
+inline Ins i_setiq(uint64_t mu) { return enc(0x0c, 0, 0, 0, 2, mu); }
+inline Ins i_break() { return enc(0x10, 0, 0, 0, 2, 0); }
+inline Ins i_vle(uint32_t vd, uint64_t ptr, uint64_t off) { return enc(0x03, vd, 0, 0, 1, (ptr << 48) | off); }
+inline Ins i_vse(uint32_t vs1, uint64_t ptr, uint64_t off) { return enc(0x07, 0, vs1, 0, 1, (ptr << 48) | off); }
+inline Ins i_vautn(uint32_t vd, uint32_t vs1, uint64_t imm) { return enc(0x1d, vd, vs1, 0, 1, imm); }
+inline Ins i_vntt(uint32_t vd, uint32_t vs1) { return enc(0x02, vd, vs1, 0, 0, 0); }
+inline Ins i_vintt(uint32_t vd, uint32_t vs1) { return enc(0x06, vd, vs1, 0, 0, 0); }
+inline Ins i_mul_vv(uint32_t vd, uint32_t a, uint32_t b) { return enc(0x01, vd, a, b, 0, 0); }
+inline Ins i_add_vv(uint32_t vd, uint32_t a, uint32_t b) { return enc(0x05, vd, a, b, 0, 0); }
+inline Ins i_mul_vs(uint32_t vd, uint32_t a, uint64_t s) { return enc(0x01, vd, a, 0, 1, s); }
+inline Ins i_add_vs(uint32_t vd, uint32_t a, uint64_t s) { return enc(0x05, vd, a, 0, 1, s); }
+inline Ins i_sub_vs(uint32_t vd, uint32_t a, uint64_t s) { return enc(0x09, vd, a, 0, 1, s); }
+
+void setq(Block &b, uint64_t q) { b.push_back(i_setq(q)); b.push_back(i_setiq(aloha::nt::barrett_mu(q))); }
+
+struct Layout {                     // aloha_amd/hybrid.py: HybridLayout
+  uint32_t n = 0, L = 0, K = 0, alpha = 0, world = 1, rank = 0, B = 1, dnum = 0, rows = 0;
+  uint64_t base_row = 0;
+  std::vector<uint64_t> moduli, specials, mods_all;
+  std::vector<uint32_t> owned_ct, owned_all, owned_sp;
+  uint32_t Lr = 0, Mr = 0, Yr = 0, Wr = 0;
+  uint64_t ct_in = 0, ct_b = 0, x = 0, rot = 0, base1 = 0, y = 0, sd = 0, acc = 0, w = 0, out = 0, s1 = 0, s2 = 0, slots = 0;
+
+  static uint32_t owner(uint32_t j, uint32_t world) { return j % world; }
+  void init() {
+    mods_all = moduli;
+    mods_all.insert(mods_all.end(), specials.begin(), specials.end());
+    dnum = (L + alpha - 1) / alpha;
+    rows = n / 128;
+    for (uint32_t j = 0; j < L + K; j++)
+      if (owner(j, world) == rank) {
+        owned_all.push_back(j);
+        if (j < L) owned_ct.push_back(j); else owned_sp.push_back(j - L);
+      }
+    Lr = (uint32_t)owned_ct.size(); Mr = (uint32_t)owned_all.size();
+    Yr = (L + world - 1) / world;
+    uint32_t most = 0;
+    for (uint32_t r = 0; r < world; r++) {
+      uint32_t c = 0;
+      for (uint32_t k = 0; k < K; k++) c += owner(L + k, world) == r;
+      most = std::max(most, c);
+    }
+    Wr = 2 * std::max(1u, most);
+    uint64_t s = 0;
+    ct_in = s; s += 2ull * Lr * B;
+    ct_b = s; s += 2ull * Lr * B;
+    x = s; s += (uint64_t)Lr * B;
+    rot = s; s += (uint64_t)Lr * B;
+    base1 = s; s += (uint64_t)Lr * B;
+    y = s; s += (uint64_t)world * Yr * B;
+    sd = s; s += (uint64_t)Mr * dnum * B;
+    acc = s; s += 2ull * Mr * B;
+    w = s; s += (uint64_t)world * Wr * B;
+    out = s; s += 2ull * Lr * B;
+    s1 = s; s += 2ull * Lr * B;
+    s2 = s; s += 2ull * Lr * B;
+    slots = s;
+  }
+  std::vector<uint32_t> digit(uint32_t d) const {
+    std::vector<uint32_t> v;
+    for (uint32_t t = d * alpha; t < std::min((d + 1) * alpha, L); t++) v.push_back(t);
+    return v;
+  }
+  bool in_digit(uint32_t j, uint32_t d) const { return j < L && j / alpha == d; }
+  uint64_t row(uint64_t slot) const { return base_row + slot * rows; }
+  uint64_t off(uint64_t slot) const { return row(slot) * 1024; }
+  uint64_t s_in(uint32_t c, uint32_t i, uint32_t b) const { return ct_in + ((uint64_t)c * Lr + i) * B + b; }
+  uint64_t s_inb(uint32_t c, uint32_t i, uint32_t b) const { return ct_b + ((uint64_t)c * Lr + i) * B + b; }
+  uint64_t s_x(uint32_t i, uint32_t b) const { return x + (uint64_t)i * B + b; }
+  uint64_t s_rot(uint32_t i, uint32_t b) const { return rot + (uint64_t)i * B + b; }
+  uint64_t s_base1(uint32_t i, uint32_t b) const { return base1 + (uint64_t)i * B + b; }
+  uint64_t s_out(uint32_t c, uint32_t i, uint32_t b) const { return out + ((uint64_t)c * Lr + i) * B + b; }
+  uint64_t s_s2(uint32_t c, uint32_t i, uint32_t b) const { return s2 + ((uint64_t)c * Lr + i) * B + b; }
+  uint64_t s_sd(uint32_t jl, uint32_t d, uint32_t b) const { return sd + ((uint64_t)jl * dnum + d) * B + b; }
+  uint64_t s_acc(uint32_t jl, uint32_t c, uint32_t b) const { return acc + (2ull * jl + c) * B + b; }
+  uint64_t y_slot(uint32_t i, uint32_t b) const { return y + ((uint64_t)owner(i, world) * Yr + i / world) * B + b; }
+  uint64_t w_slot(uint32_t k, uint32_t c, uint32_t b) const {
+    const uint32_t r = owner(L + k, world);
+    uint32_t kl = 0;
+    for (uint32_t k2 = 0; k2 < k; k2++) kl += owner(L + k2, world) == r;
+    return w + ((uint64_t)r * Wr + 2 * kl + c) * B + b;
+  }
+  uint64_t spm_rows_needed() const { return base_row + slots * rows; }
+  uint64_t ksk_limbs() const { return (uint64_t)Mr * dnum * 2; }
+  uint32_t local_ct(uint32_t j) const { for (uint32_t i = 0; i < Lr; i++) if (owned_ct[i] == j) return i; return ~0u; }
+  uint32_t local_all(uint32_t j) const { for (uint32_t i = 0; i < Mr; i++) if (owned_all[i] == j) return i; return ~0u; }
+  // prod_{t in dig, t != skip} moduli[t]  mod m
+  uint64_t prod_mod(const std::vector<uint32_t> &dig, uint32_t skip, uint64_t m) const {
+    uint64_t p = 1 % m;
+    for (uint32_t t : dig) if (t != skip) p = mulmod(p, moduli[t] % m, m);
+    return p;
+  }
+  uint64_t P_mod(uint64_t m, uint32_t skip_k = ~0u) const {      // prod_k specials[k] (k != skip_k)  mod m
+    uint64_t p = 1 % m;
+    for (uint32_t k = 0; k < K; k++) if (k != skip_k) p = mulmod(p, specials[k] % m, m);
+    return p;
+  }
+  uint64_t half_mod(uint64_t m) const {                          // floor(P/2) mod m = (P - 1) / 2 mod m  (P and m odd)
+    const uint64_t pm1 = (P_mod(m) + m - 1) % m;
+    return mulmod(pm1, (m + 1) / 2, m);
+  }
+};
+
+// dst = sum_t mem[srcs[t]] * scalars[t] [- minus] [+ plus]: a chain the sequencer evaluates in one pass (hybrid.py: _scalar_sum)
+void scalar_sum(Block &b, const std::vector<uint64_t> &srcs, const std::vector<uint64_t> &scal, uint64_t dst, bool has_minus = false,
+                uint64_t minus = 0) {
+  for (size_t t = 0; t < srcs.size(); t++) {
+    b.push_back(i_vle(0, kPtrAbs, srcs[t]));
+    if (t == 0) b.push_back(i_mul_vs(6, 0, scal[t]));
+    else { b.push_back(i_mul_vs(3, 0, scal[t])); b.push_back(i_add_vv(6, 6, 3)); }
+  }
+  if (has_minus) b.push_back(i_sub_vs(6, 6, minus));
+  b.push_back(i_vse(6, kPtrAbs, dst));
+}
+
+enum Mode { ROTATE, MULTIPLY };
+
+std::vector<Block> blocks_phase1(const Layout &lo, Mode mode) {
+  std::vector<Block> bl;
+  for (uint32_t i = 0; i < lo.Lr; i++) {
+    const uint32_t j = lo.owned_ct[i];
+    for (uint32_t bi = 0; bi < lo.B; bi++) {
+      Block b;
+      setq(b, lo.moduli[j]);
+      if (mode == ROTATE) {                                       // NTT-domain automorphism of both components
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(0, i, bi)))); b.push_back(i_vautn(2, 0, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_rot(i, bi))));
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(1, i, bi)))); b.push_back(i_vautn(2, 0, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_x(i, bi))));
+      } else {                                                    // tensor product: d0 and d2
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(0, i, bi)))); b.push_back(i_vle(1, kPtrAbs, lo.off(lo.s_inb(0, i, bi))));
+        b.push_back(i_mul_vv(2, 0, 1)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_rot(i, bi))));
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(1, i, bi)))); b.push_back(i_vle(1, kPtrAbs, lo.off(lo.s_inb(1, i, bi))));
+        b.push_back(i_mul_vv(2, 0, 1)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_x(i, bi))));
+      }
+      bl.push_back(std::move(b));
+    }
+  }
+  if (mode == MULTIPLY)
+    for (uint32_t i = 0; i < lo.Lr; i++) {                        // d1 = a0*b1 + a1*b0
+      const uint32_t j = lo.owned_ct[i];
+      for (uint32_t bi = 0; bi < lo.B; bi++) {
+        Block b;
+        setq(b, lo.moduli[j]);
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(0, i, bi)))); b.push_back(i_vle(1, kPtrAbs, lo.off(lo.s_inb(1, i, bi)))); b.push_back(i_mul_vv(6, 0, 1));
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(1, i, bi)))); b.push_back(i_vle(1, kPtrAbs, lo.off(lo.s_inb(0, i, bi)))); b.push_back(i_mul_vv(3, 0, 1));
+        b.push_back(i_add_vv(6, 6, 3)); b.push_back(i_vse(6, kPtrAbs, lo.off(lo.s_base1(i, bi))));
+        bl.push_back(std::move(b));
+      }
+    }
+  for (uint32_t i = 0; i < lo.Lr; i++) {                          // coefficient form, times (Q_d/q_j)^-1 mod q_j
+    const uint32_t j = lo.owned_ct[i];
+    const uint64_t q = lo.moduli[j];
+    const uint64_t c = invmod(lo.prod_mod(lo.digit(j / lo.alpha), j, q), q);
+    Block b;
+    setq(b, q);
+    for (uint32_t bi = 0; bi < lo.B; bi++) {
+      b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_x(i, bi)))); b.push_back(i_vintt(2, 0)); b.push_back(i_mul_vs(4, 2, c));
+      b.push_back(i_vse(4, kPtrAbs, lo.off(lo.y_slot(j, bi))));
+    }
+    bl.push_back(std::move(b));
+  }
+  return bl;
+}
+
+std::vector<Block> blocks_modup(const Layout &lo) {
+  std::vector<Block> bl;
+  for (uint32_t jl = 0; jl < lo.Mr; jl++) {                       // basis extension sums
+    const uint32_t j = lo.owned_all[jl];
+    const uint64_t m = lo.mods_all[j];
+    for (uint32_t d = 0; d < lo.dnum; d++) {
+      if (lo.in_digit(j, d)) continue;
+      const std::vector<uint32_t> dig = lo.digit(d);
+      std::vector<uint64_t> scal;
+      for (uint32_t i : dig) scal.push_back(lo.prod_mod(dig, i, m));
+      for (uint32_t bi = 0; bi < lo.B; bi++) {
+        Block b;
+        setq(b, m);
+        std::vector<uint64_t> srcs;
+        for (uint32_t i : dig) srcs.push_back(lo.off(lo.y_slot(i, bi)));
+        scalar_sum(b, srcs, scal, lo.off(lo.s_sd(jl, d, bi)));
+        bl.push_back(std::move(b));
+      }
+    }
+  }
+  for (uint32_t jl = 0; jl < lo.Mr; jl++) {                       // to NTT form, in place
+    const uint32_t j = lo.owned_all[jl];
+    Block b;
+    setq(b, lo.mods_all[j]);
+    for (uint32_t d = 0; d < lo.dnum; d++) {
+      if (lo.in_digit(j, d)) continue;
+      for (uint32_t bi = 0; bi < lo.B; bi++) {
+        const uint64_t s = lo.off(lo.s_sd(jl, d, bi));
+        b.push_back(i_vle(0, kPtrAbs, s)); b.push_back(i_vntt(2, 0)); b.push_back(i_vse(2, kPtrAbs, s));
+      }
+    }
+    bl.push_back(std::move(b));
+  }
+  return bl;
+}
+
+std::vector<Block> blocks_inner(const Layout &lo) {
+  std::vector<Block> bl;
+  for (uint32_t jl = 0; jl < lo.Mr; jl++) {
+    const uint32_t j = lo.owned_all[jl];
+    for (uint32_t bi = 0; bi < lo.B; bi++) {
+      Block b;
+      setq(b, lo.mods_all[j]);
+      for (uint32_t c = 0; c < 2; c++) {
+        const uint32_t acc = 6 + 2 * c;
+        for (uint32_t d = 0; d < lo.dnum; d++) {
+          const uint64_t src = lo.in_digit(j, d) ? lo.off(lo.s_x(lo.local_ct(j), bi)) : lo.off(lo.s_sd(jl, d, bi));
+          b.push_back(i_vle(0, kPtrAbs, src));
+          b.push_back(i_vle(1, kPtrKsk, (((uint64_t)jl * lo.dnum + d) * 2 + c) * 8 * lo.n));
+          if (d == 0) b.push_back(i_mul_vv(acc, 0, 1));
+          else { b.push_back(i_mul_vv(3, 0, 1)); b.push_back(i_add_vv(acc, acc, 3)); }
+        }
+        b.push_back(i_vse(acc, kPtrAbs, lo.off(lo.s_acc(jl, c, bi))));
+      }
+      bl.push_back(std::move(b));
+    }
+  }
+  return bl;
+}
+
+std::vector<Block> blocks_terms(const Layout &lo) {
+  std::vector<Block> bl;
+  for (uint32_t k : lo.owned_sp) {                                // one scaled inverse transform per accumulator
+    const uint64_t p = lo.specials[k];
+    const uint64_t cinv = invmod(lo.P_mod(p, k), p);
+    const uint32_t jl = lo.local_all(lo.L + k);
+    Block b;
+    setq(b, p);
+    for (uint32_t c = 0; c < 2; c++)
+      for (uint32_t bi = 0; bi < lo.B; bi++) {
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_acc(jl, c, bi)))); b.push_back(i_vintt(2, 0)); b.push_back(i_mul_vs(4, 2, cinv));
+        b.push_back(i_add_vs(4, 4, mulmod(lo.half_mod(p), cinv, p)));
+        b.push_back(i_vse(4, kPtrAbs, lo.off(lo.w_slot(k, c, bi))));
+      }
+    bl.push_back(std::move(b));
+  }
+  return bl;
+}
+
+std::vector<Block> blocks_finish(const Layout &lo, bool add_base1) {
+  std::vector<Block> bl;
+  for (uint32_t i = 0; i < lo.Lr; i++) {                          // P-basis -> q_j, minus the rounding offset
+    const uint64_t q = lo.moduli[lo.owned_ct[i]];
+    std::vector<uint64_t> scal;
+    for (uint32_t k = 0; k < lo.K; k++) scal.push_back(lo.P_mod(q, k));
+    for (uint32_t c = 0; c < 2; c++)
+      for (uint32_t bi = 0; bi < lo.B; bi++) {
+        Block b;
+        setq(b, q);
+        std::vector<uint64_t> srcs;
+        for (uint32_t k = 0; k < lo.K; k++) srcs.push_back(lo.off(lo.w_slot(k, c, bi)));
+        scalar_sum(b, srcs, scal, lo.off(lo.s_s2(c, i, bi)), true, lo.half_mod(q));
+        bl.push_back(std::move(b));
+      }
+  }
+  for (uint32_t i = 0; i < lo.Lr; i++) {                          // to NTT form, in place
+    Block b;
+    setq(b, lo.moduli[lo.owned_ct[i]]);
+    for (uint32_t c = 0; c < 2; c++)
+      for (uint32_t bi = 0; bi < lo.B; bi++) {
+        const uint64_t s = lo.off(lo.s_s2(c, i, bi));
+        b.push_back(i_vle(0, kPtrAbs, s)); b.push_back(i_vntt(2, 0)); b.push_back(i_vse(2, kPtrAbs, s));
+      }
+    bl.push_back(std::move(b));
+  }
+  for (uint32_t i = 0; i < lo.Lr; i++) {                          // (acc - t) * P^-1 + base, as a sum of scaled operands
+    const uint32_t j = lo.owned_ct[i], jl = lo.local_all(j);
+    const uint64_t q = lo.moduli[j], pinv = invmod(lo.P_mod(q), q);
+    for (uint32_t c = 0; c < 2; c++)
+      for (uint32_t bi = 0; bi < lo.B; bi++) {
+        std::vector<uint64_t> srcs = {lo.off(lo.s_acc(jl, c, bi)), lo.off(lo.s_s2(c, i, bi))}, scal = {pinv, q - pinv};
+        if (c == 0) { srcs.push_back(lo.off(lo.s_rot(i, bi))); scal.push_back(1); }
+        else if (add_base1) { srcs.push_back(lo.off(lo.s_base1(i, bi))); scal.push_back(1); }
+        Block b;
+        setq(b, q);
+        scalar_sum(b, srcs, scal, lo.off(lo.s_out(c, i, bi)));
+        bl.push_back(std::move(b));
+      }
+  }
+  return bl;
+}
+
+// greedy packing of blocks into programs that fit the 4096-word ROM (hybrid.py: _pack); a program = 3 words per instruction
+bool pack(const std::vector<Block> &blocks, uint32_t n, std::vector<std::vector<uint32_t>> *progs) {
+  std::vector<Ins> cur = {i_setvl(64ull * n)};
+  auto close = [&]() {
+    cur.push_back(i_break());
+    std::vector<uint32_t> w;
+    for (const Ins &i : cur) { w.push_back(i.inst); w.push_back((uint32_t)(i.imm >> 32)); w.push_back((uint32_t)i.imm); }
+    progs->push_back(std::move(w));
+    cur = {i_setvl(64ull * n)};
+  };
+  for (const Block &b : blocks) {
+    if (b.size() + 2 > kDepth) return false;
+    if (cur.size() + b.size() + 1 > kDepth) close();
+    cur.insert(cur.end(), b.begin(), b.end());
+  }
+  close();
+  return true;
+}
+
+// ---- RCCL, loaded on demand -------------------------------------------------------------------------------------
+struct RcclUid { char b[128]; };     // ncclUniqueId (rccl/nccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+struct Rccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, RcclUid, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+constexpr int kNcclUint64 = 5;       // ncclDataType_t: ncclUint64 (rccl/nccl.h)
+
+Rccl &rccl() {
+  static Rccl r;
+  if (r.lib) return r;
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (r.lib) break;
+  }
+  if (!r.lib) return r;
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+  r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
+  return r;
+}
+
+}  // namespace
+
+struct aloha_ks {
+  aloha_vp *vp = nullptr;          // null: a plan only (program generation and inspection)
+  Layout lo;
+  std::map<std::string, std::vector<std::vector<uint32_t>>> progs;
+  std::map<std::pair<std::string, uint32_t>, uint32_t> pc;       // resident programs
+  bool resident = false;
+  void *comm = nullptr;
+  bool own_comm = false;
+  uint64_t bytes_sent = 0, bytes_received = 0;
+  std::string err;
+};
+
+namespace {
+
+aloha_status ks_fail(aloha_ks *ks, aloha_status s, const char *fmt, ...) {
+  if (ks) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    ks->err = buf;
+  }
+  return s;
+}
+
+aloha_status check_config(const aloha_ks_config *c) {
+  if (!c || !c->moduli || !c->specials) return ALOHA_ERR_ARG;
+  if (c->log_n < 10 || c->log_n > 16) return ALOHA_ERR_VL;
+  if (!c->L || !c->K || !c->alpha || !c->world || c->rank >= c->world || !c->batch) return ALOHA_ERR_ARG;
+  if (c->L + c->K > 4096 || c->batch > 64) return ALOHA_ERR_ARG;
+  return ALOHA_OK;
+}
+
+Layout layout_of(const aloha_ks_config *c) {
+  Layout lo;
+  lo.n = 1u << c->log_n; lo.L = c->L; lo.K = c->K; lo.alpha = c->alpha; lo.world = c->world; lo.rank = c->rank; lo.B = c->batch;
+  lo.base_row = c->base_row;
+  lo.moduli.assign(c->moduli, c->moduli + c->L);
+  lo.specials.assign(c->specials, c->specials + c->K);
+  lo.init();
+  return lo;
+}
+
+aloha_status run_phase(aloha_ks *ks, const char *name, uint64_t step) {
+  auto it = ks->progs.find(name);
+  if (it == ks->progs.end()) return ALOHA_OK;
+  for (uint32_t idx = 0; idx < it->second.size(); idx++) {
+    const std::vector<uint32_t> &w = it->second[idx];
+    uint32_t pc = 0;
+    if (ks->resident) pc = ks->pc[{name, idx}];
+    else {
+      aloha_status s = aloha_vp_load_isram(ks->vp, 0, w.data(), (uint32_t)(w.size() / 3));
+      if (s) return ks_fail(ks, s, "loading phase %s[%u]: %s", name, idx, aloha_vp_last_error(ks->vp));
+    }
+    aloha_status s = aloha_vp_run(ks->vp, pc, 0, 0, 0, 0, step);
+    if (s) return ks_fail(ks, s, "phase %s[%u]: %s", name, idx, aloha_vp_last_error(ks->vp));
+  }
+  return ALOHA_OK;
+}
+
+// all-gather of `world` chunks of `chunk` words laid out back to back from SPM row `row0` (rank r owns chunk r), in place,
+// on the engine's stream: the phase's kernels precede it and the next phase's kernels follow it in stream order
+aloha_status all_gather(aloha_ks *ks, uint64_t row0, uint64_t chunk) {
+  const Layout &lo = ks->lo;
+  if (!ks->comm) return lo.world == 1 ? ALOHA_OK : ks_fail(ks, ALOHA_ERR_ARG, "world = %u but no communicator (aloha_ks_comm_init / aloha_ks_set_comm)", lo.world);
+  Rccl &r = rccl();
+  if (!r.ok) return ks_fail(ks, ALOHA_ERR_DEVICE, "librccl could not be loaded");
+  char *base = (char *)aloha_vp_device_ptr(ks->vp, ALOHA_SPACE_SPM, row0);
+  if (!base) return ks_fail(ks, ALOHA_ERR_ADDR, "gather buffer outside the SPM space");
+  const int rc = r.AllGather(base + (size_t)lo.rank * chunk * 8, base, (size_t)chunk, kNcclUint64, ks->comm, (hipStream_t)aloha_vp_stream(ks->vp));
+  if (rc) return ks_fail(ks, ALOHA_ERR_DEVICE, "ncclAllGather: %s", r.GetErrorString ? r.GetErrorString(rc) : "error");
+  ks->bytes_sent += (uint64_t)(lo.world - 1) * chunk * 8;
+  ks->bytes_received += (uint64_t)(lo.world - 1) * chunk * 8;
+  return ALOHA_OK;
+}
+
+aloha_status key_switch(aloha_ks *ks, const char *first, const char *finish, uint64_t step) {
+  const Layout &lo = ks->lo;
+  aloha_status s = run_phase(ks, first, step);
+  if (!s) s = all_gather(ks, lo.row(lo.y), (uint64_t)lo.Yr * lo.B * lo.n);
+  if (!s) s = run_phase(ks, "mid", 0);
+  if (!s) s = run_phase(ks, "terms", 0);
+  if (!s) s = all_gather(ks, lo.row(lo.w), (uint64_t)lo.Wr * lo.B * lo.n);
+  if (!s) s = run_phase(ks, finish, 0);
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+aloha_status aloha_ks_rows_needed(const aloha_ks_config *cfg, uint64_t *spm_rows, uint64_t *ksk_rows) {
+  aloha_status s = check_config(cfg);
+  if (s) return s;
+  const Layout lo = layout_of(cfg);
+  if (spm_rows) *spm_rows = lo.spm_rows_needed();
+  if (ksk_rows) *ksk_rows = std::max<uint64_t>(1, lo.ksk_limbs() * lo.rows);
+  return ALOHA_OK;
+}
+
+aloha_status aloha_ks_create(aloha_vp *vp, const aloha_ks_config *cfg, aloha_ks **out) {
+  if (!out) return ALOHA_ERR_ARG;
+  *out = nullptr;
+  aloha_status s = check_config(cfg);
+  if (s) return s;
+  aloha_ks *ks = new aloha_ks();
+  ks->vp = vp;
+  ks->lo = layout_of(cfg);
+  const Layout &lo = ks->lo;
+  bool ok = true;
+  auto add = [&](const char *name, bool cond, const std::vector<Block> &bl) {
+    std::vector<std::vector<uint32_t>> p;
+    if (cond && !pack(bl, lo.n, &p)) ok = false;
+    ks->progs[name] = std::move(p);
+  };
+  add("rot1", lo.Lr, blocks_phase1(lo, ROTATE));
+  add("mul1", lo.Lr, blocks_phase1(lo, MULTIPLY));
+  {
+    std::vector<Block> mid = blocks_modup(lo), inner = blocks_inner(lo);
+    mid.insert(mid.end(), inner.begin(), inner.end());
+    add("mid", lo.Mr, mid);
+  }
+  add("terms", !lo.owned_sp.empty(), blocks_terms(lo));
+  add("fin_rot", lo.Lr, blocks_finish(lo, false));
+  add("fin_mul", lo.Lr, blocks_finish(lo, true));
+  if (!ok) { delete ks; return ALOHA_ERR_ARG; }
+  size_t total = 0;
+  for (auto &kv : ks->progs) for (auto &w : kv.second) total += w.size() / 3;
+  ks->resident = total <= kDepth;
+  if (vp && ks->resident) {
+    uint32_t pc = 0;
+    for (auto &kv : ks->progs)
+      for (uint32_t idx = 0; idx < kv.second.size(); idx++) {
+        s = aloha_vp_load_isram(vp, pc, kv.second[idx].data(), (uint32_t)(kv.second[idx].size() / 3));
+        if (s) { delete ks; return s; }
+        ks->pc[{kv.first, idx}] = pc;
+        pc += (uint32_t)(kv.second[idx].size() / 3);
+      }
+  }
+  *out = ks;
+  return ALOHA_OK;
+}
+
+void aloha_ks_destroy(aloha_ks *ks) {
+  if (!ks) return;
+  if (ks->comm && ks->own_comm && rccl().ok) {
+    if (ks->vp) (void)aloha_vp_sync(ks->vp);
+    (void)rccl().CommDestroy(ks->comm);
+  }
+  delete ks;
+}
+
+const char *aloha_ks_last_error(const aloha_ks *ks) { return ks ? ks->err.c_str() : "null handle"; }
+
+aloha_status aloha_ks_nccl_unique_id(void *id128) {
+  if (!id128) return ALOHA_ERR_ARG;
+  Rccl &r = rccl();
+  if (!r.ok) return ALOHA_ERR_DEVICE;
+  return r.GetUniqueId(id128) ? ALOHA_ERR_DEVICE : ALOHA_OK;
+}
+
+aloha_status aloha_ks_comm_init(aloha_ks *ks, const void *id128) {
+  if (!ks || !ks->vp || !id128) return ALOHA_ERR_ARG;
+  Rccl &r = rccl();
+  if (!r.ok) return ks_fail(ks, ALOHA_ERR_DEVICE, "librccl could not be loaded");
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(aloha_vp_device(ks->vp));                   // the communicator binds to the current device
+  RcclUid uid;
+  memcpy(uid.b, id128, sizeof uid.b);
+  void *comm = nullptr;
+  const int rc = r.CommInitRank(&comm, (int)ks->lo.world, uid, (int)ks->lo.rank);
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (rc) return ks_fail(ks, ALOHA_ERR_DEVICE, "ncclCommInitRank: %s", r.GetErrorString ? r.GetErrorString(rc) : "error");
+  ks->comm = comm; ks->own_comm = true;
+  return ALOHA_OK;
+}
+
+aloha_status aloha_ks_set_comm(aloha_ks *ks, void *nccl_comm) {
+  if (!ks) return ALOHA_ERR_ARG;
+  ks->comm = nccl_comm; ks->own_comm = false;
+  return ALOHA_OK;
+}
+
+aloha_status aloha_ks_info(const aloha_ks *ks, aloha_ks_info_t *out) {
+  if (!ks || !out) return ALOHA_ERR_ARG;
+  const Layout &lo = ks->lo;
+  memset(out, 0, sizeof *out);
+  out->dnum = lo.dnum; out->owned_ct = lo.Lr; out->owned_all = lo.Mr; out->rows_per_limb = lo.rows;
+  out->spm_rows = lo.spm_rows_needed(); out->ksk_rows = std::max<uint64_t>(1, lo.ksk_limbs() * lo.rows);
+  out->resident = ks->resident ? 1 : 0;
+  out->bytes_sent = ks->bytes_sent; out->bytes_received = ks->bytes_received;
+  return ALOHA_OK;
+}
+
+aloha_status aloha_ks_owned(const aloha_ks *ks, uint32_t *ct_indices, uint32_t *all_indices) {
+  if (!ks) return ALOHA_ERR_ARG;
+  if (ct_indices) for (uint32_t i = 0; i < ks->lo.Lr; i++) ct_indices[i] = ks->lo.owned_ct[i];
+  if (all_indices) for (uint32_t i = 0; i < ks->lo.Mr; i++) all_indices[i] = ks->lo.owned_all[i];
+  return ALOHA_OK;
+}
+
+aloha_status aloha_ks_program(const aloha_ks *ks, const char *phase, uint32_t index, uint32_t *words, uint32_t *ninst) {
+  if (!ks || !phase || !ninst) return ALOHA_ERR_ARG;
+  auto it = ks->progs.find(phase);
+  if (it == ks->progs.end()) return ALOHA_ERR_ARG;
+  if (index >= it->second.size()) { *ninst = 0; return ALOHA_OK; }        // no such program: zero instructions
+  const std::vector<uint32_t> &w = it->second[index];
+  const uint32_t have = (uint32_t)(w.size() / 3), cap = *ninst;
+  *ninst = have;
+  if (words) {
+    if (cap < have) return ALOHA_ERR_ARG;
+    memcpy(words, w.data(), w.size() * 4);
+  }
+  return ALOHA_OK;
+}
+
+aloha_status aloha_ks_load_key(aloha_ks *ks, const uint64_t *key_full) {
+  if (!ks || !ks->vp || !key_full) return ALOHA_ERR_ARG;
+  const Layout &lo = ks->lo;
+  const uint64_t per = (uint64_t)lo.dnum * 2 * lo.n;             // words per modulus: [digit][component][N]
+  for (uint32_t jl = 0; jl < lo.Mr; jl++) {
+    aloha_status s = aloha_vp_write(ks->vp, ALOHA_SPACE_KSK, (uint64_t)jl * lo.dnum * 2 * lo.rows, key_full + lo.owned_all[jl] * per, per * 8);
+    if (s) return ks_fail(ks, s, "load_key: %s", aloha_vp_last_error(ks->vp));
+  }
+  return ALOHA_OK;
+}
+
+aloha_status aloha_ks_load_ct(aloha_ks *ks, int which, uint32_t slot, const uint64_t *ct_full) {
+  if (!ks || !ks->vp || !ct_full || slot >= ks->lo.B || (which != 0 && which != 1)) return ALOHA_ERR_ARG;
+  const Layout &lo = ks->lo;
+  for (uint32_t c = 0; c < 2; c++)
+    for (uint32_t i = 0; i < lo.Lr; i++) {
+      const uint64_t s_ = which ? lo.s_inb(c, i, slot) : lo.s_in(c, i, slot);
+      aloha_status s = aloha_vp_write(ks->vp, ALOHA_SPACE_SPM, lo.row(s_), ct_full + ((uint64_t)c * lo.L + lo.owned_ct[i]) * lo.n, (uint64_t)lo.n * 8);
+      if (s) return ks_fail(ks, s, "load_ct: %s", aloha_vp_last_error(ks->vp));
+    }
+  return ALOHA_OK;
+}
+
+aloha_status aloha_ks_read_out(aloha_ks *ks, uint32_t slot, uint64_t *out) {
+  if (!ks || !ks->vp || !out || slot >= ks->lo.B) return ALOHA_ERR_ARG;
+  const Layout &lo = ks->lo;
+  for (uint32_t c = 0; c < 2; c++)
+    for (uint32_t i = 0; i < lo.Lr; i++) {
+      aloha_status s = aloha_vp_read(ks->vp, ALOHA_SPACE_SPM, lo.row(lo.s_out(c, i, slot)), out + ((uint64_t)c * lo.Lr + i) * lo.n, (uint64_t)lo.n * 8);
+      if (s) return ks_fail(ks, s, "read_out: %s", aloha_vp_last_error(ks->vp));
+    }
+  return ALOHA_OK;
+}
+
+aloha_status aloha_ks_rotate(aloha_ks *ks, uint64_t k) {
+  if (!ks || !ks->vp) return ALOHA_ERR_ARG;
+  return key_switch(ks, "rot1", "fin_rot", k);
+}
+
+aloha_status aloha_ks_multiply(aloha_ks *ks) {
+  if (!ks || !ks->vp) return ALOHA_ERR_ARG;
+  return key_switch(ks, "mul1", "fin_mul", 0);
+}
+
+}  // extern "C"

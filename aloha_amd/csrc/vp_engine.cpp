@@ -557,6 +557,9 @@ void *aloha_vp_device_ptr(aloha_vp *vp, int space, uint64_t row) {
   return vp ? space_ptr(vp, space, row, 0) : nullptr;
 }
 
+void *aloha_vp_stream(aloha_vp *vp) { return vp ? (void *)vp->stream : nullptr; }
+int aloha_vp_device(const aloha_vp *vp) { return vp ? vp->device : -1; }
+
 aloha_status aloha_vp_load_isram(aloha_vp *vp, uint32_t base_pc, const uint32_t *words, uint32_t n) {
   if (!vp || !words) return ALOHA_ERR_ARG;
   if (base_pc > ALOHA_IRAM_DEPTH || n > ALOHA_IRAM_DEPTH - base_pc) return fail(vp, ALOHA_ERR_ADDR, "isram [%u, +%u) outside the %u-word ROM", base_pc, n, ALOHA_IRAM_DEPTH);

@@ -93,6 +93,9 @@ aloha_status aloha_vp_write(aloha_vp *vp, int space, uint64_t row, const void *h
 aloha_status aloha_vp_read(aloha_vp *vp, int space, uint64_t row, void *host_dst, uint64_t bytes);
 /* device address of a row, for callers that fill/consume HBM directly (zero copy) */
 void *aloha_vp_device_ptr(aloha_vp *vp, int space, uint64_t row);
+/* the HIP stream (hipStream_t) all work of the handle is enqueued on, and its device ordinal */
+void *aloha_vp_stream(aloha_vp *vp);
+int aloha_vp_device(const aloha_vp *vp);
 
 /* ---- instruction ROM ---------------------------------------------------------------------- */
 /* n words of {inst32, imm[63:32], imm[31:0]} placed at ROM address base_pc */
@@ -142,6 +145,56 @@ aloha_status aloha_vp_fill_synthetic(aloha_vp *vp, int space, uint64_t row, uint
 /* Effective VALU clock in GHz under an integer multiply-add load, measured on the handle's device for about `ms`
  * milliseconds: prices a kernel's VALU instruction count (the second bound next to HBM bandwidth). */
 aloha_status aloha_vp_valu_clock(aloha_vp *vp, double ms, double *ghz);
+
+/* ---- the L-limb key-switch as a C host (keyswitch_host.cpp) ------------------------------------------------------
+ * The reference's only cross-limb step is its rotate / key-switch micro-program (keyswitch.mem:1-122, driven by the
+ * test-bench task run_rotate, top_noaxilite_tb.sv:522-532), written for 2 ciphertext primes + 1 special prime.  These
+ * entry points generate that program for L primes, K special primes and alpha primes per digit (alpha = K = 1: the
+ * reference's algorithm), as HE-ISA phase programs run on an aloha_vp handle, with limb j living on rank j mod world
+ * and the two exchange steps (the digits, keyswitch.mem:4-43; the mod-down terms, :80-83) as ncclAllGather on the
+ * handle's stream.  RCCL is loaded on first use; world = 1 needs none.
+ *   ciphertext: 2 components x L limbs of N words, NTT form, c0 limbs then c1 limbs       (tv/README.md:4-9)
+ *   key: (L+K) x dnum x 2 limbs ordered [modulus][digit][component], dnum = ceil(L/alpha) (keyswitch.mem:46-77)
+ *   outputs: the OWNED limbs only, [component][owned index][N]; aloha_ks_owned lists the limb indices. */
+typedef struct aloha_ks aloha_ks;
+typedef struct {
+  uint32_t log_n;            /* N = 2^log_n                                                           */
+  uint32_t L, K, alpha;      /* ciphertext primes, special primes, primes per digit                   */
+  uint32_t world, rank;      /* ranks sharing the limbs, this rank                                    */
+  uint32_t batch;            /* ciphertexts switched per call under the one key (slots 0 .. batch-1)  */
+  uint32_t reserved;
+  const uint64_t *moduli;    /* L primes                                                              */
+  const uint64_t *specials;  /* K primes                                                              */
+  uint64_t base_row;         /* first SPM row the handle may use                                      */
+} aloha_ks_config;
+typedef struct {
+  uint32_t dnum, owned_ct, owned_all, rows_per_limb, resident, pad;
+  uint64_t spm_rows, ksk_rows;           /* what the aloha_vp must provide                            */
+  uint64_t bytes_sent, bytes_received;   /* exchange payload so far                                   */
+} aloha_ks_info_t;
+aloha_status aloha_ks_rows_needed(const aloha_ks_config *cfg, uint64_t *spm_rows, uint64_t *ksk_rows);
+/* vp may be NULL: a plan only -- programs are generated and can be inspected, nothing runs */
+aloha_status aloha_ks_create(aloha_vp *vp, const aloha_ks_config *cfg, aloha_ks **out);
+void aloha_ks_destroy(aloha_ks *ks);
+const char *aloha_ks_last_error(const aloha_ks *ks);
+aloha_status aloha_ks_info(const aloha_ks *ks, aloha_ks_info_t *out);
+aloha_status aloha_ks_owned(const aloha_ks *ks, uint32_t *ct_indices /* owned_ct */, uint32_t *all_indices /* owned_all */);
+/* instruction words of program `index` of a phase ("rot1", "mul1", "mid", "terms", "fin_rot", "fin_mul"); *ninst: in =
+ * capacity of `words` in instructions (3 words each), out = instructions of the program (0: no such program) */
+aloha_status aloha_ks_program(const aloha_ks *ks, const char *phase, uint32_t index, uint32_t *words, uint32_t *ninst);
+/* exchange: a 128-byte ncclUniqueId made on one rank and given to every rank's aloha_ks_comm_init (ncclCommInitRank over
+ * cfg.world ranks on the handle's device), or an existing ncclComm_t borrowed with aloha_ks_set_comm */
+aloha_status aloha_ks_nccl_unique_id(void *id128);
+aloha_status aloha_ks_comm_init(aloha_ks *ks, const void *id128);
+aloha_status aloha_ks_set_comm(aloha_ks *ks, void *nccl_comm);
+aloha_status aloha_ks_load_key(aloha_ks *ks, const uint64_t *key_full);
+aloha_status aloha_ks_load_ct(aloha_ks *ks, int which /* 0: the ciphertext, 1: the second factor of multiply */, uint32_t slot,
+                              const uint64_t *ct_full);
+aloha_status aloha_ks_read_out(aloha_ks *ks, uint32_t slot, uint64_t *out);
+/* rotate by X -> X^k and switch the key / multiply the two loaded ciphertexts and relinearise; asynchronous on the
+ * handle's stream like aloha_vp_run */
+aloha_status aloha_ks_rotate(aloha_ks *ks, uint64_t k);
+aloha_status aloha_ks_multiply(aloha_ks *ks);
 
 /* ---- parameters ------------------------------------------------------------------------------ */
 /* minimal primitive 2N-th root of unity mod q -- the rule behind the reference's hard-coded

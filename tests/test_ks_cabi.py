@@ -1,0 +1,128 @@
+"""The C host's key-switch (aloha_ks_*, csrc/keyswitch_host.cpp) against the Python generator that drives the oracle's
+ISA machine (aloha_amd/hybrid.py): on the CPU the two program generators must agree WORD FOR WORD for every phase, rank
+and layout; on the GPU the C host's results must equal the oracle machine's, with and without a (one-rank) RCCL
+communicator.  Reference step: the rotate / key-switch micro-program keyswitch.mem:1-122 and its driver run_rotate
+(top_noaxilite_tb.sv:522-532)."""
+import numpy as np
+import pytest
+
+import oracle
+from aloha_amd import hybrid, isa, ks
+from aloha_amd import vp as avp
+from util import N, P, Q0, Q1, load, manifest
+
+
+def _setup(n, L, K):
+    logn = n.bit_length() - 1
+    return [oracle.nth_prime(logn, i) for i in range(L)], [oracle.nth_prime(logn, L + k) for k in range(K)]
+
+
+PY_PHASE = {"rot1": lambda lo: hybrid.blocks_phase1(lo, "rotate"), "mul1": lambda lo: hybrid.blocks_phase1(lo, "multiply"),
+            "mid": lambda lo: hybrid.blocks_modup(lo) + hybrid.blocks_inner(lo), "terms": hybrid.blocks_moddown_terms,
+            "fin_rot": lambda lo: hybrid.blocks_finish(lo, False), "fin_mul": lambda lo: hybrid.blocks_finish(lo, True)}
+PY_COND = {"rot1": lambda lo: lo.Lr, "mul1": lambda lo: lo.Lr, "mid": lambda lo: lo.Mr, "terms": lambda lo: lo.owned_sp,
+           "fin_rot": lambda lo: lo.Lr, "fin_mul": lambda lo: lo.Lr}
+
+
+@pytest.mark.parametrize("logn,L,K,alpha,world,batch", [
+    (13, 2, 1, 1, 1, 1),       # the reference's own shape (keyswitch.mem)
+    (10, 5, 2, 2, 1, 1), (10, 5, 2, 2, 2, 1), (10, 5, 2, 2, 3, 2),
+    (12, 6, 2, 4, 1, 1),       # ragged last digit
+    (16, 24, 4, 4, 8, 1),      # BASELINE config 4 on 8 ranks
+    (16, 32, 4, 4, 8, 2), (16, 24, 1, 1, 1, 1),   # config 5; the reference's decomposition at L = 24 (programs split over the ROM)
+])
+def test_c_host_programs_equal_the_python_generator_word_for_word(logn, L, K, alpha, world, batch):
+    n = 1 << logn
+    mods, specials = _setup(n, L, K)
+    for rank in range(world):
+        lo = hybrid.HybridLayout(n, mods, specials, alpha, world, rank, base_row=7, batch=batch)
+        with ks.KeySwitch(None, logn, mods, specials, alpha, world, rank, batch, base_row=7) as k:
+            assert (k.owned_ct, k.owned_all, k.dnum) == (lo.owned_ct, lo.owned_all, lo.dnum)
+            assert ks.rows_needed(logn, mods, specials, alpha, world, rank, batch, 7) == (lo.spm_rows_needed, max(1, lo.ksk_limbs * lo.rows))
+            for phase in ks.PHASES:
+                progs = [isa.assemble("\n".join(p)) for p in hybrid._pack(PY_PHASE[phase](lo), n)] if PY_COND[phase](lo) else []
+                for idx, words in enumerate(progs):
+                    assert np.array_equal(k.program(phase, idx), words), f"rank {rank} phase {phase}[{idx}]"
+                assert k.program(phase, len(progs)).shape == (0, 3)
+
+
+def test_c_host_rejects_bad_configs():
+    mods, specials = _setup(1024, 3, 1)
+    for kw in (dict(alpha=0), dict(world=0), dict(rank=2, world=2), dict(batch=0)):
+        args = dict(alpha=1, world=1, rank=0, batch=1)
+        args.update(kw)
+        with pytest.raises(avp.AlohaError):
+            ks.KeySwitch(None, 10, mods, specials, **args)
+    with pytest.raises(avp.AlohaError):
+        ks.KeySwitch(None, 9, mods, specials, 1)
+    with ks.KeySwitch(None, 10, mods, specials, 1) as plan:      # a plan cannot run
+        with pytest.raises(avp.AlohaError):
+            plan.rotate(3)
+
+
+def _random(n, L, K, alpha, seed):
+    mods, specials = _setup(n, L, K)
+    rng = np.random.default_rng(seed)
+    dnum = -(-L // alpha)
+    ct = np.stack([rng.integers(0, mods[j % L], n, dtype=np.uint64) for j in range(2 * L)])
+    key = np.stack([rng.integers(0, (mods + specials)[j], n, dtype=np.uint64) for j in range(L + K) for _ in range(2 * dnum)])
+    return mods, specials, ct, key
+
+
+@pytest.mark.gpu
+def test_c_host_reproduces_the_golden_rotate():
+    """alpha = K = 1 with the reference's primes and key: tv/case0_4_4 kernel1 (rotation step 2 -> k = 3^2)."""
+    m = manifest()["case0"]
+    ct = load(m["kernel1_ct_before_rotate"]).reshape(4, N)
+    exp = load(m["kernel1_ct_after_rotate"]).reshape(2, 2, N)
+    spm, ksk = ks.rows_needed(13, [Q0, Q1], [P], 1)
+    with avp.VP(spm_rows=spm, ksk_rows=ksk, max_log_n=13) as vp, ks.KeySwitch(vp, 13, [Q0, Q1], [P], 1) as k:
+        k.load_key(load(m["ksk_step2"])); k.load_ct(ct)
+        k.rotate(pow(3, 2, 2 * N))
+        assert np.array_equal(k.read_out(), exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logn,L,K,alpha,batch", [(12, 5, 2, 2, 1), (16, 6, 2, 4, 2), (13, 4, 1, 1, 1)])
+def test_c_host_on_gpu_equals_oracle_machine(logn, L, K, alpha, batch):
+    n = 1 << logn
+    mods, specials, ct, key = _random(n, L, K, alpha, 300 + L)
+    cts = [np.roll(ct, b, axis=1) for b in range(batch)]
+    kk = pow(3, 5, 2 * n)
+    lo = hybrid.HybridLayout(n, mods, specials, alpha, batch=batch)
+    ref = hybrid.HybridKeySwitch(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows), n, mods, specials, alpha, batch=batch)
+    ref.load_key(key)
+    spm, ksk = ks.rows_needed(logn, mods, specials, alpha, batch=batch)
+    with avp.VP(spm_rows=spm, ksk_rows=ksk, max_log_n=logn) as vp, ks.KeySwitch(vp, logn, mods, specials, alpha, batch=batch) as k:
+        k.load_key(key.reshape(-1))
+        for b in range(batch):
+            k.load_ct(cts[b], b); k.load_ct_b(cts[b][::-1].copy(), b)
+            ref.load_ct(cts[b], b); ref.load_ct_b(cts[b][::-1].copy(), b)
+        k.rotate(kk); ref.rotate(kk)
+        for b in range(batch):
+            assert np.array_equal(k.read_out(b), ref.read_out(b)), f"rotate slot {b}"
+        k.multiply(); ref.multiply()
+        for b in range(batch):
+            assert np.array_equal(k.read_out(b), ref.read_out(b)), f"multiply slot {b}"
+
+
+@pytest.mark.gpu
+def test_c_host_with_a_one_rank_rccl_communicator():
+    """The exchange path for real: ncclGetUniqueId / ncclCommInitRank through the C ABI, both all-gathers issued as
+    ncclAllGather on the engine's stream (in place, one rank), repeated so that a missing ordering edge between a
+    phase's kernels and the collective would show.  No torch.distributed anywhere."""
+    n, logn, L, K, alpha = 1 << 13, 13, 6, 2, 2
+    mods, specials, ct, key = _random(n, L, K, alpha, 77)
+    lo = hybrid.HybridLayout(n, mods, specials, alpha)
+    ref = hybrid.HybridKeySwitch(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows), n, mods, specials, alpha)
+    ref.load_key(key); ref.load_ct(ct); ref.load_ct_b(ct[::-1].copy())
+    ref.multiply()
+    exp = ref.read_out()
+    spm, ksk = ks.rows_needed(logn, mods, specials, alpha)
+    with avp.VP(spm_rows=spm, ksk_rows=ksk, max_log_n=logn) as vp, ks.KeySwitch(vp, logn, mods, specials, alpha) as k:
+        k.comm_init(ks.nccl_unique_id())
+        k.load_key(key.reshape(-1)); k.load_ct(ct); k.load_ct_b(ct[::-1].copy())
+        for _ in range(3):
+            k.multiply()
+        assert np.array_equal(k.read_out(), exp)
+        assert k.info()["bytes_sent"] == 0                       # one rank: nothing leaves the GPU, but the collectives ran

@@ -41,6 +41,9 @@ def main() -> int:
     ap.add_argument("--batch", type=int, default=1, help="ciphertexts per call (hybrid only)")
     ap.add_argument("--p2p", action="store_true", help="all-gathers as world-1 direct sends/receives per rank instead of the collective")
     ap.add_argument("--host-sync", action="store_true", help="bracket every exchange with host synchronisation (the old path)")
+    ap.add_argument("--c-host", action="store_true",
+                    help="run the key-switch through the C host (aloha_ks_*: programs generated in C++, ncclAllGather issued by the "
+                         "library on its own communicator; torch.distributed only carries the 128-byte ncclUniqueId and the timing reduce)")
     ap.add_argument("--stub-world", type=int, default=0,
                     help="time rank 0's share of a W-rank layout on this one GPU with the exchanges skipped (results meaningless)")
     args = ap.parse_args()
@@ -71,7 +74,25 @@ def main() -> int:
     ex = keyswitch.Exchange(tensor_of=keyswitch.device_tensor if backend == "nccl" else None, always=False,
                             stream=None if (args.host_sync or backend != "nccl") else stream, stub=bool(args.stub_world), p2p=args.p2p)
 
+    class CHost:                                                 # the C host behind the call surface the script uses
+        def __init__(self, vp, w, r):
+            from aloha_amd import ks as cks
+            self.vp = vp
+            self.k = cks.KeySwitch(vp, logn, mods, specials, args.alpha, w, r, args.batch)
+            if w > 1:
+                uid = [cks.nccl_unique_id() if r == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                self.k.comm_init(uid[0])
+        def load_ct(self, ct, b=0): self.k.load_ct(ct, b)
+        def load_ct_b(self, ct, b=0): self.k.load_ct_b(ct, b)
+        def rotate(self, k): self.k.rotate(k)
+        def multiply(self): self.k.multiply()
+        def read_out(self, b=0): return self.k.read_out(b)
+
     def build(vp, w, r, exch):
+        if args.c_host:
+            assert args.alpha > 0 and args.op in ("rotate", "multiply") and not args.stub_world
+            return CHost(vp, w, r)
         if args.alpha == 0:
             return keyswitch.ShardedKeySwitch(vp, n, mods, specials[0], world=w, rank=r, exchange=exch)
         return hybrid.HybridKeySwitch(vp, n, mods, specials, args.alpha, world=w, rank=r, exchange=exch, batch=args.batch)
@@ -155,7 +176,8 @@ def main() -> int:
             ok = bool(t[0] > 0.5)
     if rank == 0:
         print(json.dumps({"metric": f"{args.op} + key-switch at N=2^{logn}", "L": L, "alpha": args.alpha, "K": K, "n_gpus": world,
-                          "batch": args.batch, "one_pass": bool(args.many), "exchange": "stubbed (rank 0's share only)" if args.stub_world else
+                          "batch": args.batch, "one_pass": bool(args.many), "host": "C (aloha_ks_*, own RCCL communicator)" if args.c_host else "python + torch.distributed",
+                          "exchange": "stubbed (rank 0's share only)" if args.stub_world else
                           ("host-synchronised" if ex.stream is None else "stream-ordered"),
                           "launches_per_op": (vp.stats()["kernel_launches"] - launches0) / args.reps,
                           "rotations_per_call": nkeys, "ms_per_rotation": elapsed / args.reps * 1e3 / nkeys,
