@@ -228,6 +228,47 @@ def keyswitch_leg(dist, backend, rank, world, local_rank):
     return res
 
 
+def keyswitch_child() -> int:
+    """One rank of the key-switch leg, in a process group of its own (see keyswitch_in_children)."""
+    import torch.distributed as dist
+    from datetime import timedelta
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    backend = os.environ.get("ALOHA_BENCH_BACKEND", "nccl")
+    local_rank = int(os.environ.get("ALOHA_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local_rank)
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=timedelta(seconds=120))
+    else:
+        dist.init_process_group(backend=backend, timeout=timedelta(seconds=120))
+    res = keyswitch_leg(dist, backend, rank, world, local_rank)
+    if rank == 0:
+        print("KEYSWITCH_JSON " + json.dumps(res), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+def keyswitch_in_children(rank: int, timeout_s: float = 300.0):
+    """The sharded key-switch leg runs in CHILD processes with a rendezvous of their own (every rank of this run starts
+    one and waits for it with a time limit): its collectives have never met more than one GPU at the time of writing,
+    and a failure or a hang there must not cost the headline line -- it becomes {"error": ...} in the `keyswitch` object."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str((int(os.environ.get("MASTER_PORT", "29500")) + 1009) % 60000 + 2048)
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:   # (under torchrun the agent's store serves MASTER_PORT only:
+        env.pop(k)                                                #  without these rank 0 of the child group hosts its own)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--keyswitch-child"], env=env, capture_output=True, text=True,
+                           timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"key-switch leg did not finish within {timeout_s:.0f} s (killed)"}
+    if rank != 0:
+        return None
+    for line in p.stdout.splitlines():
+        if line.startswith("KEYSWITCH_JSON "):
+            return json.loads(line[len("KEYSWITCH_JSON "):])
+    return {"error": f"key-switch leg exited with code {p.returncode}", "stderr_tail": p.stderr[-600:]}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,7 +280,10 @@ def main() -> int:
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle loop (A/B: shows the clock transient)")
     ap.add_argument("--no-keyswitch", action="store_true", help="N > 1 only: skip the sharded key-switch leg")
     ap.add_argument("--inverse", action="store_true", help="time vintt instead (side metric; headline is forward)")
+    ap.add_argument("--keyswitch-child", action="store_true", help=argparse.SUPPRESS)   # internal: one rank of the key-switch leg
     args = ap.parse_args()
+    if args.keyswitch_child:
+        return keyswitch_child()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(sys.argv[1:], args.gpus)             # nothing above has touched the GPU
@@ -335,7 +379,7 @@ def main() -> int:
 
     ks = None
     if dist is not None and world > 1 and not args.no_keyswitch:
-        ks = keyswitch_leg(dist, backend, rank, world, local_rank)
+        ks = keyswitch_in_children(rank)
 
     if rank == 0:
         total_ntts = world * B * args.steps

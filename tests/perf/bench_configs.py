@@ -120,11 +120,15 @@ def config45(L):
         l0 = vp.stats()["kernel_launches"]
         tm = timeit(lambda: ks.multiply(), vp.sync, 5)
         launches_mul = (vp.stats()["kernel_launches"] - l0) / 6
+        # phase 1 with the automorphism in the NTT domain (keyswitch.py: reference_shape=False): L transforms instead of 3L
+        ks2 = keyswitch.ShardedKeySwitch(vp, n, mods, special, reference_shape=False)
+        ks2.rotate(k); vp.sync()
+        t_nd = timeit(lambda: ks2.rotate(k), vp.sync, 5)
         transforms = 2 * L + L * (L + 1) + L + 2 * (1 + L)          # rotate: iNTT c0,c1; digits x moduli; NTT rotated c0; mod-down
         transforms_mul = L + L * (L + 1) + 2 * (1 + L)              # product: iNTT d2; digits x moduli; mod-down
         # algorithmic bytes of the product: transforms*16N + key 2*L*(L+1)*8N + tensor (4 in, 3 out)*8N*L
         alg = (transforms_mul * 16 + 2 * L * (L + 1) * 8 + 7 * 8 * L) * n
-    return {"L": L, "rotate_keyswitch_ms": t * 1e3, "transforms_per_rotate": transforms,
+    return {"L": L, "rotate_keyswitch_ms": t * 1e3, "rotate_keyswitch_ms_ntt_domain_phase1": t_nd * 1e3, "transforms_per_rotate": transforms,
             "transform_equiv_per_s": transforms / t, "kernel_launches_per_rotate": launches_rot,
             "hmult_relin_ms": tm * 1e3, "transforms_per_hmult": transforms_mul, "kernel_launches_per_hmult": launches_mul,
             "hmult_algorithmic_GBps": alg / tm / 1e9}
