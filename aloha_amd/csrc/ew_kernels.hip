@@ -13,6 +13,8 @@ namespace k {
 
 namespace {
 
+constexpr uint32_t kMaxGridY = 65535;       // batched kernels carry the job index in gridDim.y
+
 struct alignas(16) u64x2 { u64 x, y; };
 
 template <int OP>
@@ -367,12 +369,14 @@ hipError_t ew_batch(hipStream_t st, const EwJob *d_jobs, uint32_t njobs, uint32_
   const uint32_t n2 = n / 2;
   uint32_t gx = grid_for(n2);
   if (njobs >= 64 && gx > 32) gx = 32;             // enough blocks already: keep per-job grids short
-  hipLaunchKernelGGL(ew_batch_kernel, dim3(gx, njobs), dim3(256), 0, st, d_jobs, n2);
+  for (uint32_t off = 0; off < njobs; off += kMaxGridY)
+    hipLaunchKernelGGL(ew_batch_kernel, dim3(gx, std::min(kMaxGridY, njobs - off)), dim3(256), 0, st, d_jobs + off, n2);
   return hipGetLastError();
 }
 
 hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsigned logn, bool two_pass) {
   if (!njobs) return hipSuccess;
+  if (two_pass && njobs > kMaxGridY) two_pass = false;            // (a program holds < 1400 such jobs; the gather form below chunks)
   const uint32_t n = 1u << logn;
   if (two_pass && logn >= 12 && logn <= 16) {          // automorphisms only (no rolls), R = N/256 >= 16 rows
     hipLaunchKernelGGL(aut_rows_kernel, dim3(n >> 12, njobs), dim3(256), 0, st, d_jobs, n);
@@ -385,7 +389,8 @@ hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsig
   }
   uint32_t gx = grid_for(n);
   if (njobs >= 64 && gx > 64) gx = 64;
-  hipLaunchKernelGGL(aut_batch_kernel, dim3(gx, njobs), dim3(256), 0, st, d_jobs, n);
+  for (uint32_t off = 0; off < njobs; off += kMaxGridY)           // (gridDim.y carries the job index)
+    hipLaunchKernelGGL(aut_batch_kernel, dim3(gx, std::min(kMaxGridY, njobs - off)), dim3(256), 0, st, d_jobs + off, n);
   return hipGetLastError();
 }
 
@@ -400,7 +405,8 @@ hipError_t dot_batch(hipStream_t st, const DotArgs *d_jobs, uint32_t njobs, uint
   const uint32_t n2 = n / 2;
   uint32_t gx = grid_for(n2);
   while (gx > 16 && (uint64_t)gx * njobs > 8192) gx /= 2;    // plenty of workgroups already: longer grid-stride loops instead
-  hipLaunchKernelGGL(dot_batch_kernel, dim3(gx, njobs), dim3(256), 0, st, d_jobs, n2);
+  for (uint32_t off = 0; off < njobs; off += kMaxGridY)
+    hipLaunchKernelGGL(dot_batch_kernel, dim3(gx, std::min(kMaxGridY, njobs - off)), dim3(256), 0, st, d_jobs + off, n2);
   return hipGetLastError();
 }
 
@@ -409,7 +415,8 @@ hipError_t sum_groups(hipStream_t st, const SumGroup *d_groups, uint32_t ngroups
   const uint32_t n2 = n / 2;
   uint32_t gx = (n2 + 255) / 256;                            // one element pair per thread: the loop over outputs is the work
   if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(sum_group_kernel, dim3(gx ? gx : 1, ngroups), dim3(256), 0, st, d_groups, d_jobs, n2);
+  for (uint32_t off = 0; off < ngroups; off += kMaxGridY)
+    hipLaunchKernelGGL(sum_group_kernel, dim3(gx ? gx : 1, std::min(kMaxGridY, ngroups - off)), dim3(256), 0, st, d_groups + off, d_jobs, n2);
   return hipGetLastError();
 }
 

@@ -880,15 +880,19 @@ hipError_t ntt_radix2_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDe
                             bool first_reads_src, bool last_scales, uint64_t *launches) {
   // forward: stages s = stage_begin .. stage_end-1 (s = 0 is the stride-N/2 stage)
   // inverse: stages u = stage_begin .. stage_end-1 (u = 0 is the stride-1 stage)
-  const dim3 grid((1u << logn) / 2 / 256, count), blk(256);
+  // the job index rides in gridDim.y (<= 65535): larger batches go stage by stage in chunks of that many limbs
+  constexpr uint32_t kMaxY = 65535;
   for (unsigned s = stage_begin; s < stage_end; s++) {
     const int first = (first_reads_src && s == stage_begin) ? 1 : 0;
-    if (!inverse)
-      hipLaunchKernelGGL(ntt_radix2_fwd_stage, grid, blk, 0, st, d_jobs, d_primes, logn, s, first);
-    else
-      hipLaunchKernelGGL(ntt_radix2_inv_stage, grid, blk, 0, st, d_jobs, d_primes, logn, s, first,
-                         (last_scales && s + 1 == stage_end) ? 1 : 0);
-    if (launches) ++*launches;
+    for (uint32_t off = 0; off < count; off += kMaxY) {
+      const dim3 grid((1u << logn) / 2 / 256, std::min(kMaxY, count - off)), blk(256);
+      if (!inverse)
+        hipLaunchKernelGGL(ntt_radix2_fwd_stage, grid, blk, 0, st, d_jobs + off, d_primes, logn, s, first);
+      else
+        hipLaunchKernelGGL(ntt_radix2_inv_stage, grid, blk, 0, st, d_jobs + off, d_primes, logn, s, first,
+                           (last_scales && s + 1 == stage_end) ? 1 : 0);
+      if (launches) ++*launches;
+    }
   }
   return hipGetLastError();
 }

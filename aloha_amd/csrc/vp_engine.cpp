@@ -265,6 +265,7 @@ aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
   PrimeSlot ps;
   ps.q = q; ps.logn = logn;
   HIPCK(vp, hipMalloc(&ps.d_tables, host.size() * 8));
+  struct Undo { u64 *&p; bool armed = true; ~Undo() { if (armed && p) { (void)hipFree(p); p = nullptr; } } } undo{ps.d_tables};   // no leak on the error paths below
   HIPCK(vp, hipMemcpyAsync(ps.d_tables, host.data(), host.size() * 8, hipMemcpyHostToDevice, vp->stream));
   HIPCK(vp, hipStreamSynchronize(vp->stream));      // `host` goes out of scope
   ps.dev.m = modctx(q);
@@ -279,6 +280,7 @@ aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
   const uint32_t idx = (uint32_t)vp->slots.size();
   HIPCK(vp, hipMemcpyAsync(vp->d_primes + idx, &ps.dev, sizeof(PrimeDev), hipMemcpyHostToDevice, vp->stream));
   HIPCK(vp, hipStreamSynchronize(vp->stream));
+  undo.armed = false;
   vp->slots.push_back(ps);
   vp->slot_of[key] = idx;
   vp->stats.twiddle_builds++;

@@ -841,3 +841,21 @@ def test_recorded_runs_survive_cache_evictions():
         vp.sync()
         for i in (0, 1, 2, 699, 0):
             check(i)
+
+
+def test_more_than_65535_limbs_in_one_batch():
+    """the stage kernels of N < 2^12 carry the limb index in gridDim.y (<= 65535); a larger batch used to pass
+    validation and fail at launch.  70 000 limbs of N = 1024: spot checks against the oracle across the chunk boundary
+    and a full round trip."""
+    logn, n, count = 10, 1024, 70000
+    q = oracle.nth_prime(10, 0)
+    rng = np.random.default_rng(65535)
+    data = rng.integers(0, q, (count, n), dtype=np.uint64)
+    with avp.VP(spm_rows=count * n // 128, ksk_rows=1, max_log_n=10) as vp:
+        vp.write(SPM, 0, data.reshape(-1))
+        vp.ntt_rows(SPM, 0, 0, logn, [q] * count)
+        got = vp.read(SPM, 0, count * n).reshape(count, n)
+        for i in (0, 65534, 65535, 65536, 69999):
+            assert np.array_equal(got[i], oracle.ntt(data[i], q)), i
+        vp.ntt_rows(SPM, 0, 0, logn, [q] * count, inverse=True)
+        assert np.array_equal(vp.read(SPM, 0, count * n).reshape(count, n), data)
