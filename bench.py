@@ -228,6 +228,52 @@ def keyswitch_leg(dist, backend, rank, world, local_rank):
     return res
 
 
+def keyswitch_leg_c_host(dist, rank, world, local_rank):
+    """The same operation through the C host (aloha_ks_*, csrc/keyswitch_host.cpp): programs generated in C++, the two
+    all-gathers issued by the library as ncclAllGather on a communicator of its own.  torch.distributed (gloo) only
+    carries the 128-byte ncclUniqueId and the timing reduce.  Verified against a single-rank C host on every rank."""
+    from aloha_amd import ks as cks
+    from aloha_amd import vp as avp
+    L, alpha, reps = 24, 4, 10
+    mods = [avp.nth_prime(LOGN, i) for i in range(L)]
+    specials = [avp.nth_prime(LOGN, L + k) for k in range(alpha)]
+    dnum = -(-L // alpha)
+    ct = np.stack([np.random.default_rng(539 + j).integers(0, mods[j % L], N, dtype=np.uint64) for j in range(2 * L)])
+
+    def make(w, r, uid):
+        spm, ksk = cks.rows_needed(LOGN, mods, specials, alpha, w, r)
+        vp = avp.VP(spm_rows=spm, ksk_rows=ksk, max_log_n=LOGN, device=local_rank)
+        k = cks.KeySwitch(vp, LOGN, mods, specials, alpha, w, r)
+        if uid is not None:
+            k.comm_init(uid)
+        for jl, j in enumerate(k.owned_all):                     # key words depend on the modulus only (as in keyswitch_leg)
+            vp.write(1, jl * dnum * 2 * (N // 128), np.random.default_rng(7000 + j).integers(0, (mods + specials)[j], dnum * 2 * N, dtype=np.uint64))
+        k.load_ct(ct); k.load_ct_b(ct[::-1].copy())
+        return vp, k
+
+    uid = [cks.nccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    vp, k = make(world, rank, uid[0])
+    k.multiply(); vp.sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        k.multiply()
+    vp.sync()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out, owned, info = k.read_out(), list(k.owned_ct), k.info()
+    k.close(); vp.close()
+    vp1, k1 = make(1, 0, None)
+    k1.multiply()
+    ref = k1.read_out()
+    k1.close(); vp1.close()
+    ok = torch.tensor([1.0 if all(np.array_equal(out[:, i], ref[:, j]) for i, j in enumerate(owned)) else 0.0], dtype=torch.float64)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return {"ms": float(t[0]) / reps * 1e3, "verified": bool(ok[0] > 0.5), "bytes_sent_per_rank": info["bytes_sent"] // (reps + 1),
+            "exchange": "ncclAllGather issued by the C host on its own communicator, stream-ordered"}
+
+
 def keyswitch_child() -> int:
     """One rank of the key-switch leg, in a process group of its own (see keyswitch_in_children)."""
     import torch.distributed as dist
@@ -236,11 +282,12 @@ def keyswitch_child() -> int:
     backend = os.environ.get("ALOHA_BENCH_BACKEND", "nccl")
     local_rank = int(os.environ.get("ALOHA_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local_rank)
-    if backend == "nccl":
+    c_host = os.environ.get("ALOHA_KS_CHILD_MODE") == "c_host"
+    if backend == "nccl" and not c_host:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=timedelta(seconds=120))
-    else:
-        dist.init_process_group(backend=backend, timeout=timedelta(seconds=120))
-    res = keyswitch_leg(dist, backend, rank, world, local_rank)
+    else:                                                        # the C host brings its own RCCL communicator: gloo carries the id and the timings
+        dist.init_process_group(backend="gloo", timeout=timedelta(seconds=120))
+    res = keyswitch_leg_c_host(dist, rank, world, local_rank) if c_host else keyswitch_leg(dist, backend, rank, world, local_rank)
     if rank == 0:
         print("KEYSWITCH_JSON " + json.dumps(res), flush=True)
     dist.destroy_process_group()
@@ -252,21 +299,32 @@ def keyswitch_in_children(rank: int, timeout_s: float = 300.0):
     one and waits for it with a time limit): its collectives have never met more than one GPU at the time of writing,
     and a failure or a hang there must not cost the headline line -- it becomes {"error": ...} in the `keyswitch` object."""
     import subprocess
-    env = dict(os.environ)
-    env["MASTER_PORT"] = str((int(os.environ.get("MASTER_PORT", "29500")) + 1009) % 60000 + 2048)
-    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:   # (under torchrun the agent's store serves MASTER_PORT only:
-        env.pop(k)                                                #  without these rank 0 of the child group hosts its own)
-    try:
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--keyswitch-child"], env=env, capture_output=True, text=True,
-                           timeout=timeout_s)
-    except subprocess.TimeoutExpired:
-        return {"error": f"key-switch leg did not finish within {timeout_s:.0f} s (killed)"}
+
+    def child(mode: str, port_shift: int):
+        env = dict(os.environ)
+        env["MASTER_PORT"] = str((int(os.environ.get("MASTER_PORT", "29500")) + port_shift) % 60000 + 2048)
+        env["ALOHA_KS_CHILD_MODE"] = mode
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:   # (under torchrun the agent's store serves MASTER_PORT only:
+            env.pop(k)                                                #  without these rank 0 of the child group hosts its own)
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--keyswitch-child"], env=env, capture_output=True, text=True,
+                               timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return {"error": f"did not finish within {timeout_s:.0f} s (killed)"}
+        for line in p.stdout.splitlines():
+            if line.startswith("KEYSWITCH_JSON "):
+                return json.loads(line[len("KEYSWITCH_JSON "):])
+        return {"error": f"exited with code {p.returncode}", "stderr_tail": p.stderr[-600:]}
+
+    res = child("torch", 1009)                                   # Python host + torch.distributed (collective and point-to-point)
+    c_host = None
+    if os.environ.get("ALOHA_BENCH_BACKEND", "nccl") == "nccl":  # (two ranks of a rehearsal on ONE GPU cannot form an RCCL communicator)
+        c_host = child("c_host", 2027)
     if rank != 0:
         return None
-    for line in p.stdout.splitlines():
-        if line.startswith("KEYSWITCH_JSON "):
-            return json.loads(line[len("KEYSWITCH_JSON "):])
-    return {"error": f"key-switch leg exited with code {p.returncode}", "stderr_tail": p.stderr[-600:]}
+    if c_host is not None:
+        res["c_host"] = c_host
+    return res
 
 
 def main() -> int:
