@@ -120,7 +120,9 @@ struct Layout {                     // aloha_amd/hybrid.py: HybridLayout
   uint64_t s_rot(uint32_t i, uint32_t b) const { return rot + (uint64_t)i * B + b; }
   uint64_t s_base1(uint32_t i, uint32_t b) const { return base1 + (uint64_t)i * B + b; }
   uint64_t s_out(uint32_t c, uint32_t i, uint32_t b) const { return out + ((uint64_t)c * Lr + i) * B + b; }
+  uint64_t s_s1(uint32_t c, uint32_t i, uint32_t b) const { return s1 + ((uint64_t)c * Lr + i) * B + b; }
   uint64_t s_s2(uint32_t c, uint32_t i, uint32_t b) const { return s2 + ((uint64_t)c * Lr + i) * B + b; }
+  uint64_t rescale_slot(uint32_t c, uint32_t b) const { return w + ((uint64_t)owner(L - 1, world) * Wr + c) * B + b; }
   uint64_t s_sd(uint32_t jl, uint32_t d, uint32_t b) const { return sd + ((uint64_t)jl * dnum + d) * B + b; }
   uint64_t s_acc(uint32_t jl, uint32_t c, uint32_t b) const { return acc + (2ull * jl + c) * B + b; }
   uint64_t y_slot(uint32_t i, uint32_t b) const { return y + ((uint64_t)owner(i, world) * Yr + i / world) * B + b; }
@@ -163,31 +165,36 @@ void scalar_sum(Block &b, const std::vector<uint64_t> &srcs, const std::vector<u
   b.push_back(i_vse(6, kPtrAbs, dst));
 }
 
-enum Mode { ROTATE, MULTIPLY };
+enum Mode { ROTATE, MULTIPLY, HOIST };
 
-std::vector<Block> blocks_phase1(const Layout &lo, Mode mode) {
+// ciphertext slots a loop covers: all `B` of them, or the first `nb` only (hoist_one: slot 0 is the decomposed
+// ciphertext, the other slots serve as rotation slots)
+struct Slots { uint32_t nb; };
+
+std::vector<Block> blocks_phase1(const Layout &lo, Mode mode, Slots sl) {
   std::vector<Block> bl;
-  for (uint32_t i = 0; i < lo.Lr; i++) {
-    const uint32_t j = lo.owned_ct[i];
-    for (uint32_t bi = 0; bi < lo.B; bi++) {
-      Block b;
-      setq(b, lo.moduli[j]);
-      if (mode == ROTATE) {                                       // NTT-domain automorphism of both components
-        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(0, i, bi)))); b.push_back(i_vautn(2, 0, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_rot(i, bi))));
-        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(1, i, bi)))); b.push_back(i_vautn(2, 0, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_x(i, bi))));
-      } else {                                                    // tensor product: d0 and d2
-        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(0, i, bi)))); b.push_back(i_vle(1, kPtrAbs, lo.off(lo.s_inb(0, i, bi))));
-        b.push_back(i_mul_vv(2, 0, 1)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_rot(i, bi))));
-        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(1, i, bi)))); b.push_back(i_vle(1, kPtrAbs, lo.off(lo.s_inb(1, i, bi))));
-        b.push_back(i_mul_vv(2, 0, 1)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_x(i, bi))));
+  if (mode != HOIST)
+    for (uint32_t i = 0; i < lo.Lr; i++) {
+      const uint32_t j = lo.owned_ct[i];
+      for (uint32_t bi = 0; bi < sl.nb; bi++) {
+        Block b;
+        setq(b, lo.moduli[j]);
+        if (mode == ROTATE) {                                     // NTT-domain automorphism of both components
+          b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(0, i, bi)))); b.push_back(i_vautn(2, 0, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_rot(i, bi))));
+          b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(1, i, bi)))); b.push_back(i_vautn(2, 0, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_x(i, bi))));
+        } else {                                                  // tensor product: d0 and d2
+          b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(0, i, bi)))); b.push_back(i_vle(1, kPtrAbs, lo.off(lo.s_inb(0, i, bi))));
+          b.push_back(i_mul_vv(2, 0, 1)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_rot(i, bi))));
+          b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(1, i, bi)))); b.push_back(i_vle(1, kPtrAbs, lo.off(lo.s_inb(1, i, bi))));
+          b.push_back(i_mul_vv(2, 0, 1)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_x(i, bi))));
+        }
+        bl.push_back(std::move(b));
       }
-      bl.push_back(std::move(b));
     }
-  }
   if (mode == MULTIPLY)
     for (uint32_t i = 0; i < lo.Lr; i++) {                        // d1 = a0*b1 + a1*b0
       const uint32_t j = lo.owned_ct[i];
-      for (uint32_t bi = 0; bi < lo.B; bi++) {
+      for (uint32_t bi = 0; bi < sl.nb; bi++) {
         Block b;
         setq(b, lo.moduli[j]);
         b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(0, i, bi)))); b.push_back(i_vle(1, kPtrAbs, lo.off(lo.s_inb(1, i, bi)))); b.push_back(i_mul_vv(6, 0, 1));
@@ -202,8 +209,9 @@ std::vector<Block> blocks_phase1(const Layout &lo, Mode mode) {
     const uint64_t c = invmod(lo.prod_mod(lo.digit(j / lo.alpha), j, q), q);
     Block b;
     setq(b, q);
-    for (uint32_t bi = 0; bi < lo.B; bi++) {
-      b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_x(i, bi)))); b.push_back(i_vintt(2, 0)); b.push_back(i_mul_vs(4, 2, c));
+    for (uint32_t bi = 0; bi < sl.nb; bi++) {
+      const uint64_t x = mode == HOIST ? lo.s_in(1, i, bi) : lo.s_x(i, bi);     // hoisted: c1 itself, not rotated
+      b.push_back(i_vle(0, kPtrAbs, lo.off(x))); b.push_back(i_vintt(2, 0)); b.push_back(i_mul_vs(4, 2, c));
       b.push_back(i_vse(4, kPtrAbs, lo.off(lo.y_slot(j, bi))));
     }
     bl.push_back(std::move(b));
@@ -211,7 +219,7 @@ std::vector<Block> blocks_phase1(const Layout &lo, Mode mode) {
   return bl;
 }
 
-std::vector<Block> blocks_modup(const Layout &lo) {
+std::vector<Block> blocks_modup(const Layout &lo, Slots sl) {
   std::vector<Block> bl;
   for (uint32_t jl = 0; jl < lo.Mr; jl++) {                       // basis extension sums
     const uint32_t j = lo.owned_all[jl];
@@ -221,7 +229,7 @@ std::vector<Block> blocks_modup(const Layout &lo) {
       const std::vector<uint32_t> dig = lo.digit(d);
       std::vector<uint64_t> scal;
       for (uint32_t i : dig) scal.push_back(lo.prod_mod(dig, i, m));
-      for (uint32_t bi = 0; bi < lo.B; bi++) {
+      for (uint32_t bi = 0; bi < sl.nb; bi++) {
         Block b;
         setq(b, m);
         std::vector<uint64_t> srcs;
@@ -237,7 +245,7 @@ std::vector<Block> blocks_modup(const Layout &lo) {
     setq(b, lo.mods_all[j]);
     for (uint32_t d = 0; d < lo.dnum; d++) {
       if (lo.in_digit(j, d)) continue;
-      for (uint32_t bi = 0; bi < lo.B; bi++) {
+      for (uint32_t bi = 0; bi < sl.nb; bi++) {
         const uint64_t s = lo.off(lo.s_sd(jl, d, bi));
         b.push_back(i_vle(0, kPtrAbs, s)); b.push_back(i_vntt(2, 0)); b.push_back(i_vse(2, kPtrAbs, s));
       }
@@ -247,19 +255,26 @@ std::vector<Block> blocks_modup(const Layout &lo) {
   return bl;
 }
 
-std::vector<Block> blocks_inner(const Layout &lo) {
+// regions (hoisted rotations in one pass): slot b is rotation b of the ONE decomposed ciphertext in slot 0, with its key
+// in key region regions[b]
+std::vector<Block> blocks_inner(const Layout &lo, bool hoisted, const std::vector<uint32_t> *regions) {
   std::vector<Block> bl;
+  const uint32_t nb = regions ? (uint32_t)regions->size() : lo.B;
   for (uint32_t jl = 0; jl < lo.Mr; jl++) {
     const uint32_t j = lo.owned_all[jl];
-    for (uint32_t bi = 0; bi < lo.B; bi++) {
+    for (uint32_t bi = 0; bi < nb; bi++) {
       Block b;
       setq(b, lo.mods_all[j]);
+      const uint32_t sb = regions ? 0 : bi;                       // operand slot
+      const uint64_t kb = regions ? (uint64_t)(*regions)[bi] * lo.ksk_limbs() : 0;
       for (uint32_t c = 0; c < 2; c++) {
         const uint32_t acc = 6 + 2 * c;
         for (uint32_t d = 0; d < lo.dnum; d++) {
-          const uint64_t src = lo.in_digit(j, d) ? lo.off(lo.s_x(lo.local_ct(j), bi)) : lo.off(lo.s_sd(jl, d, bi));
+          uint64_t src;
+          if (lo.in_digit(j, d)) src = lo.off(hoisted ? lo.s_in(1, lo.local_ct(j), sb) : lo.s_x(lo.local_ct(j), sb));
+          else src = lo.off(lo.s_sd(jl, d, sb));
           b.push_back(i_vle(0, kPtrAbs, src));
-          b.push_back(i_vle(1, kPtrKsk, (((uint64_t)jl * lo.dnum + d) * 2 + c) * 8 * lo.n));
+          b.push_back(i_vle(1, kPtrKsk, (kb + ((uint64_t)jl * lo.dnum + d) * 2 + c) * 8 * lo.n));
           if (d == 0) b.push_back(i_mul_vv(acc, 0, 1));
           else { b.push_back(i_mul_vv(3, 0, 1)); b.push_back(i_add_vv(acc, acc, 3)); }
         }
@@ -271,7 +286,7 @@ std::vector<Block> blocks_inner(const Layout &lo) {
   return bl;
 }
 
-std::vector<Block> blocks_terms(const Layout &lo) {
+std::vector<Block> blocks_terms(const Layout &lo, Slots sl) {
   std::vector<Block> bl;
   for (uint32_t k : lo.owned_sp) {                                // one scaled inverse transform per accumulator
     const uint64_t p = lo.specials[k];
@@ -280,7 +295,7 @@ std::vector<Block> blocks_terms(const Layout &lo) {
     Block b;
     setq(b, p);
     for (uint32_t c = 0; c < 2; c++)
-      for (uint32_t bi = 0; bi < lo.B; bi++) {
+      for (uint32_t bi = 0; bi < sl.nb; bi++) {
         b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_acc(jl, c, bi)))); b.push_back(i_vintt(2, 0)); b.push_back(i_mul_vs(4, 2, cinv));
         b.push_back(i_add_vs(4, 4, mulmod(lo.half_mod(p), cinv, p)));
         b.push_back(i_vse(4, kPtrAbs, lo.off(lo.w_slot(k, c, bi))));
@@ -290,14 +305,17 @@ std::vector<Block> blocks_terms(const Layout &lo) {
   return bl;
 }
 
-std::vector<Block> blocks_finish(const Layout &lo, bool add_base1) {
+// hoisted: base_0 is the unrotated c0 and the automorphism (vautn, CSR step) is applied to both results last;
+// steps: slot b is rotation steps[b] of the ciphertext in slot 0 (the step rides in the instruction's immediate)
+std::vector<Block> blocks_finish(const Layout &lo, bool add_base1, bool hoisted, const std::vector<uint64_t> *steps) {
   std::vector<Block> bl;
+  const uint32_t nb = steps ? (uint32_t)steps->size() : lo.B;
   for (uint32_t i = 0; i < lo.Lr; i++) {                          // P-basis -> q_j, minus the rounding offset
     const uint64_t q = lo.moduli[lo.owned_ct[i]];
     std::vector<uint64_t> scal;
     for (uint32_t k = 0; k < lo.K; k++) scal.push_back(lo.P_mod(q, k));
     for (uint32_t c = 0; c < 2; c++)
-      for (uint32_t bi = 0; bi < lo.B; bi++) {
+      for (uint32_t bi = 0; bi < nb; bi++) {
         Block b;
         setq(b, q);
         std::vector<uint64_t> srcs;
@@ -310,7 +328,7 @@ std::vector<Block> blocks_finish(const Layout &lo, bool add_base1) {
     Block b;
     setq(b, lo.moduli[lo.owned_ct[i]]);
     for (uint32_t c = 0; c < 2; c++)
-      for (uint32_t bi = 0; bi < lo.B; bi++) {
+      for (uint32_t bi = 0; bi < nb; bi++) {
         const uint64_t s = lo.off(lo.s_s2(c, i, bi));
         b.push_back(i_vle(0, kPtrAbs, s)); b.push_back(i_vntt(2, 0)); b.push_back(i_vse(2, kPtrAbs, s));
       }
@@ -320,17 +338,81 @@ std::vector<Block> blocks_finish(const Layout &lo, bool add_base1) {
     const uint32_t j = lo.owned_ct[i], jl = lo.local_all(j);
     const uint64_t q = lo.moduli[j], pinv = invmod(lo.P_mod(q), q);
     for (uint32_t c = 0; c < 2; c++)
-      for (uint32_t bi = 0; bi < lo.B; bi++) {
+      for (uint32_t bi = 0; bi < nb; bi++) {
         std::vector<uint64_t> srcs = {lo.off(lo.s_acc(jl, c, bi)), lo.off(lo.s_s2(c, i, bi))}, scal = {pinv, q - pinv};
-        if (c == 0) { srcs.push_back(lo.off(lo.s_rot(i, bi))); scal.push_back(1); }
+        if (c == 0) { srcs.push_back(lo.off(hoisted ? lo.s_in(0, i, steps ? 0 : bi) : lo.s_rot(i, bi))); scal.push_back(1); }
         else if (add_base1) { srcs.push_back(lo.off(lo.s_base1(i, bi))); scal.push_back(1); }
         Block b;
         setq(b, q);
-        scalar_sum(b, srcs, scal, lo.off(lo.s_out(c, i, bi)));
+        scalar_sum(b, srcs, scal, lo.off(hoisted ? lo.s_s1(c, i, bi) : lo.s_out(c, i, bi)));
         bl.push_back(std::move(b));
       }
   }
+  if (hoisted)
+    for (uint32_t i = 0; i < lo.Lr; i++) {
+      Block b;
+      setq(b, lo.moduli[lo.owned_ct[i]]);
+      for (uint32_t c = 0; c < 2; c++)
+        for (uint32_t bi = 0; bi < nb; bi++) {
+          b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_s1(c, i, bi)))); b.push_back(i_vautn(2, 0, steps ? (*steps)[bi] : 0));
+          b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_out(c, i, bi))));
+        }
+      bl.push_back(std::move(b));
+    }
   return bl;
+}
+
+// rescale by the last ciphertext prime (hybrid.py: blocks_rescale): [blocks of the owner of q_last, blocks of every rank]
+void blocks_rescale(const Layout &lo, std::vector<Block> *first, std::vector<Block> *second) {
+  const uint32_t L = lo.L;
+  const uint64_t qL = lo.moduli[L - 1], half = qL / 2;
+  const uint32_t iL = lo.local_ct(L - 1);
+  if (iL != ~0u) {
+    Block b;
+    setq(b, qL);
+    for (uint32_t c = 0; c < 2; c++)
+      for (uint32_t bi = 0; bi < lo.B; bi++) {
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(c, iL, bi)))); b.push_back(i_vintt(2, 0)); b.push_back(i_mul_vs(4, 2, 1));
+        b.push_back(i_add_vs(4, 4, half)); b.push_back(i_vse(4, kPtrAbs, lo.off(lo.rescale_slot(c, bi))));
+      }
+    first->push_back(std::move(b));
+  }
+  for (uint32_t i = 0; i < lo.Lr; i++) {
+    const uint32_t j = lo.owned_ct[i];
+    if (j == L - 1) continue;
+    const uint64_t q = lo.moduli[j];
+    for (uint32_t c = 0; c < 2; c++)
+      for (uint32_t bi = 0; bi < lo.B; bi++) {                    // t mod q_j, minus the rounding offset
+        Block b;
+        setq(b, q);
+        scalar_sum(b, {lo.off(lo.rescale_slot(c, bi))}, {1}, lo.off(lo.s_s2(c, i, bi)), true, half % q);
+        second->push_back(std::move(b));
+      }
+  }
+  for (uint32_t i = 0; i < lo.Lr; i++) {
+    const uint32_t j = lo.owned_ct[i];
+    if (j == L - 1) continue;
+    Block b;
+    setq(b, lo.moduli[j]);
+    for (uint32_t c = 0; c < 2; c++)
+      for (uint32_t bi = 0; bi < lo.B; bi++) {
+        const uint64_t s = lo.off(lo.s_s2(c, i, bi));
+        b.push_back(i_vle(0, kPtrAbs, s)); b.push_back(i_vntt(2, 0)); b.push_back(i_vse(2, kPtrAbs, s));
+      }
+    second->push_back(std::move(b));
+  }
+  for (uint32_t i = 0; i < lo.Lr; i++) {
+    const uint32_t j = lo.owned_ct[i];
+    if (j == L - 1) continue;
+    const uint64_t q = lo.moduli[j], inv = invmod(qL % q, q);
+    for (uint32_t c = 0; c < 2; c++)
+      for (uint32_t bi = 0; bi < lo.B; bi++) {
+        Block b;
+        setq(b, q);
+        scalar_sum(b, {lo.off(lo.s_in(c, i, bi)), lo.off(lo.s_s2(c, i, bi))}, {inv, q - inv}, lo.off(lo.s_out(c, i, bi)));
+        second->push_back(std::move(b));
+      }
+  }
 }
 
 // greedy packing of blocks into programs that fit the 4096-word ROM (hybrid.py: _pack); a program = 3 words per instruction
@@ -393,6 +475,7 @@ struct aloha_ks {
   void *comm = nullptr;
   bool own_comm = false;
   uint64_t bytes_sent = 0, bytes_received = 0;
+  std::string many_key;            // (steps, regions) the "many*" programs were generated for
   std::string err;
 };
 
@@ -428,7 +511,7 @@ Layout layout_of(const aloha_ks_config *c) {
   return lo;
 }
 
-aloha_status run_phase(aloha_ks *ks, const char *name, uint64_t step) {
+aloha_status run_phase(aloha_ks *ks, const char *name, uint64_t step, uint64_t ksk_row = 0) {
   auto it = ks->progs.find(name);
   if (it == ks->progs.end()) return ALOHA_OK;
   for (uint32_t idx = 0; idx < it->second.size(); idx++) {
@@ -439,7 +522,7 @@ aloha_status run_phase(aloha_ks *ks, const char *name, uint64_t step) {
       aloha_status s = aloha_vp_load_isram(ks->vp, 0, w.data(), (uint32_t)(w.size() / 3));
       if (s) return ks_fail(ks, s, "loading phase %s[%u]: %s", name, idx, aloha_vp_last_error(ks->vp));
     }
-    aloha_status s = aloha_vp_run(ks->vp, pc, 0, 0, 0, 0, step);
+    aloha_status s = aloha_vp_run(ks->vp, pc, 0, 0, 0, ksk_row, step);
     if (s) return ks_fail(ks, s, "phase %s[%u]: %s", name, idx, aloha_vp_last_error(ks->vp));
   }
   return ALOHA_OK;
@@ -500,16 +583,28 @@ aloha_status aloha_ks_create(aloha_vp *vp, const aloha_ks_config *cfg, aloha_ks 
     if (cond && !pack(bl, lo.n, &p)) ok = false;
     ks->progs[name] = std::move(p);
   };
-  add("rot1", lo.Lr, blocks_phase1(lo, ROTATE));
-  add("mul1", lo.Lr, blocks_phase1(lo, MULTIPLY));
+  const Slots all{lo.B};
+  add("rot1", lo.Lr, blocks_phase1(lo, ROTATE, all));
+  add("mul1", lo.Lr, blocks_phase1(lo, MULTIPLY, all));
   {
-    std::vector<Block> mid = blocks_modup(lo), inner = blocks_inner(lo);
+    std::vector<Block> mid = blocks_modup(lo, all), inner = blocks_inner(lo, false, nullptr);
     mid.insert(mid.end(), inner.begin(), inner.end());
     add("mid", lo.Mr, mid);
   }
-  add("terms", !lo.owned_sp.empty(), blocks_terms(lo));
-  add("fin_rot", lo.Lr, blocks_finish(lo, false));
-  add("fin_mul", lo.Lr, blocks_finish(lo, true));
+  add("terms", !lo.owned_sp.empty(), blocks_terms(lo, all));
+  add("fin_rot", lo.Lr, blocks_finish(lo, false, false, nullptr));
+  add("fin_mul", lo.Lr, blocks_finish(lo, true, false, nullptr));
+  // hoisted rotations (one decomposition, many steps) and the rescale of leveled CKKS
+  add("hoist1", lo.Lr, blocks_phase1(lo, HOIST, all));
+  add("modup", lo.Mr, blocks_modup(lo, all));
+  add("inner_h", lo.Mr, blocks_inner(lo, true, nullptr));
+  add("fin_h", lo.Lr, blocks_finish(lo, false, true, nullptr));
+  {
+    std::vector<Block> r1, r2;
+    blocks_rescale(lo, &r1, &r2);
+    add("rescale1", !r1.empty(), r1);
+    add("rescale2", !r2.empty(), r2);
+  }
   if (!ok) { delete ks; return ALOHA_ERR_ARG; }
   size_t total = 0;
   for (auto &kv : ks->progs) for (auto &w : kv.second) total += w.size() / 3;
@@ -576,6 +671,7 @@ aloha_status aloha_ks_info(const aloha_ks *ks, aloha_ks_info_t *out) {
   out->dnum = lo.dnum; out->owned_ct = lo.Lr; out->owned_all = lo.Mr; out->rows_per_limb = lo.rows;
   out->spm_rows = lo.spm_rows_needed(); out->ksk_rows = std::max<uint64_t>(1, lo.ksk_limbs() * lo.rows);
   out->resident = ks->resident ? 1 : 0;
+  out->key_rows = lo.ksk_limbs() * lo.rows;
   out->bytes_sent = ks->bytes_sent; out->bytes_received = ks->bytes_received;
   return ALOHA_OK;
 }
@@ -644,6 +740,100 @@ aloha_status aloha_ks_rotate(aloha_ks *ks, uint64_t k) {
 aloha_status aloha_ks_multiply(aloha_ks *ks) {
   if (!ks || !ks->vp) return ALOHA_ERR_ARG;
   return key_switch(ks, "mul1", "fin_mul", 0);
+}
+
+/* ---- hoisted rotations: one decomposition of the ciphertext, many rotation steps (hybrid.py: hoist / rotate_hoisted /
+ * rotate_hoisted_many; BASELINE config 5 is a BATCH of rotations) -------------------------------------------------- */
+aloha_status aloha_ks_load_key_hoisted(aloha_ks *ks, const uint64_t *key_full, uint64_t k, uint32_t index) {
+  if (!ks || !ks->vp || !key_full || !(k & 1)) return ALOHA_ERR_ARG;
+  const Layout &lo = ks->lo;
+  // stored as sigma_k^-1(KEY): in NTT form a pure permutation of positions, position j <- brv(((2 brv(j) + 1) k^-1 mod 2N - 1) / 2)
+  const uint32_t n = lo.n, bits = 31 - (uint32_t)__builtin_clz(n);
+  uint64_t kinv = 1;                                              // inverse of k mod 2N (Newton: doubles the correct bits)
+  for (int it = 0; it < 6; it++) kinv = kinv * (2 - k * kinv);
+  kinv &= 2ull * n - 1;
+  std::vector<uint32_t> src(n);
+  for (uint32_t j = 0; j < n; j++) {
+    const uint64_t e = ((2ull * aloha::nt::bitrev(j, bits) + 1) * kinv) & (2ull * n - 1);
+    src[j] = aloha::nt::bitrev((uint32_t)((e - 1) >> 1), bits);
+  }
+  const uint64_t per = (uint64_t)lo.dnum * 2 * n, key_rows = lo.ksk_limbs() * lo.rows;
+  std::vector<uint64_t> buf(per);
+  for (uint32_t jl = 0; jl < lo.Mr; jl++) {
+    const uint64_t *from = key_full + lo.owned_all[jl] * per;
+    for (uint64_t limb = 0; limb < (uint64_t)lo.dnum * 2; limb++)
+      for (uint32_t j = 0; j < n; j++) buf[limb * n + j] = from[limb * n + src[j]];
+    aloha_status s = aloha_vp_write(ks->vp, ALOHA_SPACE_KSK, index * key_rows + (uint64_t)jl * lo.dnum * 2 * lo.rows, buf.data(), per * 8);
+    if (s) return ks_fail(ks, s, "load_key_hoisted: %s", aloha_vp_last_error(ks->vp));
+  }
+  return ALOHA_OK;
+}
+
+// programs generated after create (hoist of slot 0 only; rotations in one pass) are not resident: from then on every
+// program is loaded at address 0 before it runs, as in hybrid.py
+static bool set_dynamic(aloha_ks *ks, const char *name, bool cond, const std::vector<Block> &bl) {
+  std::vector<std::vector<uint32_t>> p;
+  if (cond && !pack(bl, ks->lo.n, &p)) return false;
+  ks->progs[name] = std::move(p);
+  ks->resident = false;
+  return true;
+}
+
+aloha_status aloha_ks_hoist(aloha_ks *ks, int first_slot_only) {
+  if (!ks) return ALOHA_ERR_ARG;
+  const Layout &lo = ks->lo;
+  if (first_slot_only && !ks->progs.count("hoist1_1")) {
+    if (!set_dynamic(ks, "hoist1_1", lo.Lr, blocks_phase1(lo, HOIST, Slots{1})) || !set_dynamic(ks, "modup_1", lo.Mr, blocks_modup(lo, Slots{1})))
+      return ks_fail(ks, ALOHA_ERR_ARG, "a block exceeds the instruction ROM");
+  }
+  if (!ks->vp) return ALOHA_OK;                                   // a plan: programs only
+  aloha_status s = run_phase(ks, first_slot_only ? "hoist1_1" : "hoist1", 0);
+  if (!s) s = all_gather(ks, lo.row(lo.y), (uint64_t)lo.Yr * lo.B * lo.n);
+  if (!s) s = run_phase(ks, first_slot_only ? "modup_1" : "modup", 0);
+  return s;
+}
+
+aloha_status aloha_ks_rotate_hoisted(aloha_ks *ks, uint64_t k, uint32_t index) {
+  if (!ks || !ks->vp) return ALOHA_ERR_ARG;
+  const Layout &lo = ks->lo;
+  aloha_status s = run_phase(ks, "inner_h", 0, index * lo.ksk_limbs() * lo.rows);
+  if (!s) s = run_phase(ks, "terms", 0);
+  if (!s) s = all_gather(ks, lo.row(lo.w), (uint64_t)lo.Wr * lo.B * lo.n);
+  if (!s) s = run_phase(ks, "fin_h", k);
+  return s;
+}
+
+aloha_status aloha_ks_rotate_hoisted_many(aloha_ks *ks, const uint64_t *steps, const uint32_t *regions, uint32_t count) {
+  if (!ks || !steps || !count || count > ks->lo.B) return ALOHA_ERR_ARG;
+  const Layout &lo = ks->lo;
+  std::vector<uint64_t> st(steps, steps + count);
+  std::vector<uint32_t> rg(count);
+  for (uint32_t i = 0; i < count; i++) rg[i] = regions ? regions[i] : i;
+  std::string key = "many";
+  for (uint32_t i = 0; i < count; i++) key += ":" + std::to_string(st[i]) + "@" + std::to_string(rg[i]);
+  if (ks->many_key != key) {
+    if (!set_dynamic(ks, "many", lo.Mr, blocks_inner(lo, true, &rg)) || !set_dynamic(ks, "many_terms", !lo.owned_sp.empty(), blocks_terms(lo, Slots{count})) ||
+        !set_dynamic(ks, "many_fin", lo.Lr, blocks_finish(lo, false, true, &st)))
+      return ks_fail(ks, ALOHA_ERR_ARG, "a block exceeds the instruction ROM");
+    ks->many_key = key;
+  }
+  if (!ks->vp) return ALOHA_OK;
+  aloha_status s = run_phase(ks, "many", 0);
+  if (!s) s = run_phase(ks, "many_terms", 0);
+  if (!s) s = all_gather(ks, lo.row(lo.w), (uint64_t)lo.Wr * lo.B * lo.n);
+  if (!s) s = run_phase(ks, "many_fin", 0);
+  return s;
+}
+
+/* CT (slot-wise, L limbs) -> OUT (limbs 0 .. L-2 valid): rounded division by the last ciphertext prime -- the step after
+ * a product in leveled CKKS; one all-gather of the coefficient-form last limb (2 x batch limbs) */
+aloha_status aloha_ks_rescale(aloha_ks *ks) {
+  if (!ks || !ks->vp) return ALOHA_ERR_ARG;
+  const Layout &lo = ks->lo;
+  aloha_status s = run_phase(ks, "rescale1", 0);
+  if (!s) s = all_gather(ks, lo.row(lo.w), (uint64_t)lo.Wr * lo.B * lo.n);
+  if (!s) s = run_phase(ks, "rescale2", 0);
+  return s;
 }
 
 }  // extern "C"

@@ -23,13 +23,14 @@ class _KsConfig(C.Structure):
 class _KsInfo(C.Structure):
     _fields_ = [("dnum", C.c_uint32), ("owned_ct", C.c_uint32), ("owned_all", C.c_uint32), ("rows_per_limb", C.c_uint32),
                 ("resident", C.c_uint32), ("pad", C.c_uint32), ("spm_rows", C.c_uint64), ("ksk_rows", C.c_uint64),
-                ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64)]
+                ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64), ("key_rows", C.c_uint64)]
 
 
 EXPORTS = ["aloha_ks_rows_needed", "aloha_ks_create", "aloha_ks_destroy", "aloha_ks_last_error", "aloha_ks_info", "aloha_ks_owned",
            "aloha_ks_program", "aloha_ks_nccl_unique_id", "aloha_ks_comm_init", "aloha_ks_set_comm", "aloha_ks_load_key",
-           "aloha_ks_load_ct", "aloha_ks_read_out", "aloha_ks_rotate", "aloha_ks_multiply", "aloha_vp_stream", "aloha_vp_device"]
-PHASES = ("rot1", "mul1", "mid", "terms", "fin_rot", "fin_mul")
+           "aloha_ks_load_ct", "aloha_ks_read_out", "aloha_ks_rotate", "aloha_ks_multiply", "aloha_ks_load_key_hoisted", "aloha_ks_hoist",
+           "aloha_ks_rotate_hoisted", "aloha_ks_rotate_hoisted_many", "aloha_ks_rescale", "aloha_vp_stream", "aloha_vp_device"]
+PHASES = ("rot1", "mul1", "mid", "terms", "fin_rot", "fin_mul", "hoist1", "modup", "inner_h", "fin_h", "rescale1", "rescale2")
 _bound = False
 
 
@@ -53,6 +54,11 @@ def _lib():
         L.aloha_ks_read_out.restype = i; L.aloha_ks_read_out.argtypes = [p, u32, p]
         L.aloha_ks_rotate.restype = i; L.aloha_ks_rotate.argtypes = [p, u64]
         L.aloha_ks_multiply.restype = i; L.aloha_ks_multiply.argtypes = [p]
+        L.aloha_ks_load_key_hoisted.restype = i; L.aloha_ks_load_key_hoisted.argtypes = [p, p, u64, u32]
+        L.aloha_ks_hoist.restype = i; L.aloha_ks_hoist.argtypes = [p, i]
+        L.aloha_ks_rotate_hoisted.restype = i; L.aloha_ks_rotate_hoisted.argtypes = [p, u64, u32]
+        L.aloha_ks_rotate_hoisted_many.restype = i; L.aloha_ks_rotate_hoisted_many.argtypes = [p, p, p, u32]
+        L.aloha_ks_rescale.restype = i; L.aloha_ks_rescale.argtypes = [p]
         L.aloha_vp_stream.restype = p; L.aloha_vp_stream.argtypes = [p]
         L.aloha_vp_device.restype = i; L.aloha_vp_device.argtypes = [p]
         _bound = True
@@ -166,3 +172,22 @@ class KeySwitch:
 
     def multiply(self) -> None:
         self._chk(self._L.aloha_ks_multiply(self._h))
+
+    # -- hoisted rotations, rescale ---------------------------------------------------------------
+    def load_key_hoisted(self, key_full, k: int, region: int) -> None:
+        kf = np.ascontiguousarray(key_full, dtype=np.uint64)
+        self._chk(self._L.aloha_ks_load_key_hoisted(self._h, kf.ctypes.data, int(k), region))
+
+    def hoist(self, first_slot_only: bool = False) -> None:
+        self._chk(self._L.aloha_ks_hoist(self._h, int(first_slot_only)))
+
+    def rotate_hoisted(self, k: int, region: int) -> None:
+        self._chk(self._L.aloha_ks_rotate_hoisted(self._h, int(k), region))
+
+    def rotate_hoisted_many(self, steps: Sequence[int], regions: Optional[Sequence[int]] = None) -> None:
+        st = (C.c_uint64 * len(steps))(*[int(x) for x in steps])
+        rg = (C.c_uint32 * len(steps))(*[int(x) for x in regions]) if regions is not None else None
+        self._chk(self._L.aloha_ks_rotate_hoisted_many(self._h, st, rg, len(steps)))
+
+    def rescale(self) -> None:
+        self._chk(self._L.aloha_ks_rescale(self._h))

@@ -169,8 +169,9 @@ typedef struct {
 } aloha_ks_config;
 typedef struct {
   uint32_t dnum, owned_ct, owned_all, rows_per_limb, resident, pad;
-  uint64_t spm_rows, ksk_rows;           /* what the aloha_vp must provide                            */
+  uint64_t spm_rows, ksk_rows;           /* what the aloha_vp must provide (ksk_rows: ONE key region)  */
   uint64_t bytes_sent, bytes_received;   /* exchange payload so far                                   */
+  uint64_t key_rows;                     /* KSK rows of one key region (hoisted rotations keep one key per region) */
 } aloha_ks_info_t;
 aloha_status aloha_ks_rows_needed(const aloha_ks_config *cfg, uint64_t *spm_rows, uint64_t *ksk_rows);
 /* vp may be NULL: a plan only -- programs are generated and can be inspected, nothing runs */
@@ -179,7 +180,9 @@ void aloha_ks_destroy(aloha_ks *ks);
 const char *aloha_ks_last_error(const aloha_ks *ks);
 aloha_status aloha_ks_info(const aloha_ks *ks, aloha_ks_info_t *out);
 aloha_status aloha_ks_owned(const aloha_ks *ks, uint32_t *ct_indices /* owned_ct */, uint32_t *all_indices /* owned_all */);
-/* instruction words of program `index` of a phase ("rot1", "mul1", "mid", "terms", "fin_rot", "fin_mul"); *ninst: in =
+/* instruction words of program `index` of a phase ("rot1", "mul1", "mid", "terms", "fin_rot", "fin_mul", "hoist1", "modup",
+ * "inner_h", "fin_h", "rescale1", "rescale2"; after aloha_ks_hoist(.., 1): "hoist1_1", "modup_1"; after
+ * aloha_ks_rotate_hoisted_many: "many", "many_terms", "many_fin" -- both also generate on a plan); *ninst: in =
  * capacity of `words` in instructions (3 words each), out = instructions of the program (0: no such program) */
 aloha_status aloha_ks_program(const aloha_ks *ks, const char *phase, uint32_t index, uint32_t *words, uint32_t *ninst);
 /* exchange: a 128-byte ncclUniqueId made on one rank and given to every rank's aloha_ks_comm_init (ncclCommInitRank over
@@ -195,6 +198,17 @@ aloha_status aloha_ks_read_out(aloha_ks *ks, uint32_t slot, uint64_t *out);
  * handle's stream like aloha_vp_run */
 aloha_status aloha_ks_rotate(aloha_ks *ks, uint64_t k);
 aloha_status aloha_ks_multiply(aloha_ks *ks);
+/* Hoisted rotations (BASELINE config 5 is a BATCH of rotations): decompose the ciphertext once -- aloha_ks_hoist; with
+ * first_slot_only the other batch slots become ROTATION slots -- then rotate by many steps, each with its own key stored
+ * by aloha_ks_load_key_hoisted(key, k, region) in KSK region `region` (regions are key_rows apart; the aloha_vp needs
+ * regions x ksk_rows): one step at a time (aloha_ks_rotate_hoisted) or `count` <= batch steps in ONE pass of the phases,
+ * OUT slot b = rotation by steps[b] with the key of regions[b] (NULL: region b). */
+aloha_status aloha_ks_load_key_hoisted(aloha_ks *ks, const uint64_t *key_full, uint64_t k, uint32_t region);
+aloha_status aloha_ks_hoist(aloha_ks *ks, int first_slot_only);
+aloha_status aloha_ks_rotate_hoisted(aloha_ks *ks, uint64_t k, uint32_t region);
+aloha_status aloha_ks_rotate_hoisted_many(aloha_ks *ks, const uint64_t *steps, const uint32_t *regions, uint32_t count);
+/* rounded division by the last ciphertext prime (the step after a product in leveled CKKS): OUT limbs 0 .. L-2 */
+aloha_status aloha_ks_rescale(aloha_ks *ks);
 
 /* ---- parameters ------------------------------------------------------------------------------ */
 /* minimal primitive 2N-th root of unity mod q -- the rule behind the reference's hard-coded

@@ -20,8 +20,13 @@ def _setup(n, L, K):
 PY_PHASE = {"rot1": lambda lo: hybrid.blocks_phase1(lo, "rotate"), "mul1": lambda lo: hybrid.blocks_phase1(lo, "multiply"),
             "mid": lambda lo: hybrid.blocks_modup(lo) + hybrid.blocks_inner(lo), "terms": hybrid.blocks_moddown_terms,
             "fin_rot": lambda lo: hybrid.blocks_finish(lo, False), "fin_mul": lambda lo: hybrid.blocks_finish(lo, True)}
+PY_PHASE.update({"hoist1": lambda lo: hybrid.blocks_phase1(lo, "hoist"), "modup": hybrid.blocks_modup,
+                 "inner_h": lambda lo: hybrid.blocks_inner(lo, True), "fin_h": lambda lo: hybrid.blocks_finish(lo, False, True),
+                 "rescale1": lambda lo: hybrid.blocks_rescale(lo)[0], "rescale2": lambda lo: hybrid.blocks_rescale(lo)[1]})
 PY_COND = {"rot1": lambda lo: lo.Lr, "mul1": lambda lo: lo.Lr, "mid": lambda lo: lo.Mr, "terms": lambda lo: lo.owned_sp,
-           "fin_rot": lambda lo: lo.Lr, "fin_mul": lambda lo: lo.Lr}
+           "fin_rot": lambda lo: lo.Lr, "fin_mul": lambda lo: lo.Lr, "hoist1": lambda lo: lo.Lr, "modup": lambda lo: lo.Mr,
+           "inner_h": lambda lo: lo.Mr, "fin_h": lambda lo: lo.Lr, "rescale1": lambda lo: hybrid.blocks_rescale(lo)[0],
+           "rescale2": lambda lo: hybrid.blocks_rescale(lo)[1]}
 
 
 @pytest.mark.parametrize("logn,L,K,alpha,world,batch", [
@@ -41,6 +46,20 @@ def test_c_host_programs_equal_the_python_generator_word_for_word(logn, L, K, al
             assert ks.rows_needed(logn, mods, specials, alpha, world, rank, batch, 7) == (lo.spm_rows_needed, max(1, lo.ksk_limbs * lo.rows))
             for phase in ks.PHASES:
                 progs = [isa.assemble("\n".join(p)) for p in hybrid._pack(PY_PHASE[phase](lo), n)] if PY_COND[phase](lo) else []
+                for idx, words in enumerate(progs):
+                    assert np.array_equal(k.program(phase, idx), words), f"rank {rank} phase {phase}[{idx}]"
+                assert k.program(phase, len(progs)).shape == (0, 3)
+            # programs generated on demand: the decomposition of slot 0 only, and `batch` rotations in one pass
+            k.hoist(first_slot_only=True)
+            steps = [pow(3, b + 2, 2 * n) for b in range(batch)]
+            regions = list(range(batch))[::-1]
+            k.rotate_hoisted_many(steps, regions)
+            R = range(batch)
+            dyn = {"hoist1_1": (lo.Lr, hybrid.blocks_phase1(lo, "hoist", range(1))), "modup_1": (lo.Mr, hybrid.blocks_modup(lo, range(1))),
+                   "many": (lo.Mr, hybrid.blocks_inner(lo, True, regions)), "many_terms": (lo.owned_sp, hybrid.blocks_moddown_terms(lo, R)),
+                   "many_fin": (lo.Lr, hybrid.blocks_finish(lo, False, True, steps))}
+            for phase, (cond, blocks) in dyn.items():
+                progs = [isa.assemble("\n".join(p)) for p in hybrid._pack(blocks, n)] if cond else []
                 for idx, words in enumerate(progs):
                     assert np.array_equal(k.program(phase, idx), words), f"rank {rank} phase {phase}[{idx}]"
                 assert k.program(phase, len(progs)).shape == (0, 3)
@@ -126,3 +145,35 @@ def test_c_host_with_a_one_rank_rccl_communicator():
             k.multiply()
         assert np.array_equal(k.read_out(), exp)
         assert k.info()["bytes_sent"] == 0                       # one rank: nothing leaves the GPU, but the collectives ran
+
+
+@pytest.mark.gpu
+def test_c_host_hoisted_rotations_and_rescale_equal_oracle_machine():
+    """One decomposition, three rotation steps (one at a time, and all in ONE pass of the phases with one key region per
+    step), then the rescale of leveled CKKS: the C host on the GPU == hybrid.py on the oracle's ISA machine."""
+    logn, n, L, K, alpha, R = 13, 1 << 13, 6, 2, 2, 3
+    mods, specials, ct, key = _random(n, L, K, alpha, 91)
+    keys = [np.roll(key, r + 1, axis=1) for r in range(R)]
+    steps = [pow(3, r + 1, 2 * n) for r in range(R)]
+    lo = hybrid.HybridLayout(n, mods, specials, alpha, batch=R)
+    ref = hybrid.HybridKeySwitch(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=R * lo.ksk_limbs * lo.rows), n, mods, specials, alpha, batch=R)
+    spm, ksk = ks.rows_needed(logn, mods, specials, alpha, batch=R)
+    with avp.VP(spm_rows=spm, ksk_rows=R * ksk, max_log_n=logn) as vp, ks.KeySwitch(vp, logn, mods, specials, alpha, batch=R) as k:
+        assert k.info()["key_rows"] == ref.key_rows == ksk
+        for r in range(R):
+            k.load_key_hoisted(keys[r].reshape(-1), steps[r], r); ref.load_key_hoisted(keys[r], steps[r], r)
+        for b in range(R):
+            c = np.roll(ct, b, axis=1)
+            k.load_ct(c, b); ref.load_ct(c, b)
+        k.hoist(); ref.hoist()
+        for r in range(R):
+            k.rotate_hoisted(steps[r], r); ref.rotate_hoisted(steps[r], r)
+            for b in range(R):
+                assert np.array_equal(k.read_out(b), ref.read_out(b)), f"hoisted step {r} slot {b}"
+        k.hoist(first_slot_only=True); ref.hoist_one()
+        k.rotate_hoisted_many(steps, [2, 0, 1]); ref.rotate_hoisted_many(steps, [2, 0, 1])
+        for b in range(R):
+            assert np.array_equal(k.read_out(b), ref.read_out(b)), f"one-pass rotation slot {b}"
+        k.rescale(); ref.rescale()
+        for b in range(R):
+            assert np.array_equal(k.read_out(b)[:, :L - 1], ref.read_out(b)[:, :L - 1]), f"rescale slot {b}"
