@@ -58,6 +58,7 @@ struct PlanChunk {               // limbs [limb_begin, +limb_count) and their ro
 
 struct TransformPlan {           // device-side description of one batched transform, cached
   std::vector<LimbJob> jobs;     // 2*count entries: {src,dst} then the in-place form {dst,dst}
+  uint64_t key_hash = 0;         // hash of the first `count` jobs: the cache compares it before the job arrays themselves
   unsigned logn = 0;
   std::vector<PlanChunk> chunks; // empty => radix-2 stage launches only
   LimbJob *d_jobs = nullptr;
@@ -309,12 +310,19 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
   // Plans (device job/tile arrays + chunk schedule) are cached: a steady-state caller that
   // repeats a batch pays only for the kernel launches.
   TransformPlan *plan = nullptr;
+  uint64_t key_hash = 0xcbf29ce484222325ull;         // (one pass over the jobs instead of a memcmp against every cached array)
+  for (uint32_t i = 0; i < count; i++) {
+    const LimbJob &j = jobs1[i];
+    for (uint64_t x : {(uint64_t)(uintptr_t)j.src, (uint64_t)(uintptr_t)j.dst, ((uint64_t)j.prime << 1) | j.scaled, (uint64_t)j.sc[0], (uint64_t)j.sc[2], (uint64_t)j.addc})
+      key_hash = (key_hash ^ x) * 0x100000001b3ull;
+  }
   for (auto &p : vp->plans)
-    if (p->logn == logn && p->jobs.size() == 2 * (size_t)count &&
+    if (p->key_hash == key_hash && p->logn == logn && p->jobs.size() == 2 * (size_t)count &&
         memcmp(p->jobs.data(), jobs1.data(), count * sizeof(LimbJob)) == 0) { plan = p.get(); break; }
   if (!plan) {
     std::unique_ptr<TransformPlan> np(new TransformPlan());
     np->logn = logn;
+    np->key_hash = key_hash;
     np->jobs = jobs1;
     np->jobs.resize(2 * (size_t)count);
     for (uint32_t i = 0; i < count; i++) { np->jobs[count + i] = jobs1[i]; np->jobs[count + i].src = jobs1[i].dst; }
