@@ -53,7 +53,24 @@ namespace k {
 namespace {
 
 constexpr int LINES = 16;          // lines per column tile
-constexpr int PITCH = 257;         // column-tile LDS pitch in u64: odd => conflict-free 64-bit accesses
+// Column-tile LDS image.  Default: pitch 257 words (odd => conflict-free 64-bit accesses), 32896 B, 4 workgroups per CU.
+// ALOHA_COL5=1 (experiment): no padding -- 32768 B, FIVE workgroups fit the 160 KiB exactly -- and an XOR swizzle of the
+// row index instead: g(col) = (col & 7) << 1 | (col >> 3) * 0b10001 keeps both mappings conflict-free (in the A
+// mapping a half-wave varies row bit 0 and the column, in the B mapping row bit 4 and the column; bit 3 of the column
+// is folded into both); the forward kernel then preloads 7 of its 15 second-step twiddles to stay within 96 VGPRs.
+#ifndef ALOHA_COL5
+#define ALOHA_COL5 0
+#endif
+#ifndef ALOHA_SETPRIO
+#define ALOHA_SETPRIO 0
+#endif
+#if ALOHA_COL5
+constexpr int PITCH = 256;
+__device__ __forceinline__ uint32_t cswz(uint32_t col) { return ((col & 7) << 1) | ((col >> 3) * 17u); }
+#else
+constexpr int PITCH = 257;
+__device__ __forceinline__ uint32_t cswz(uint32_t) { return 0; }
+#endif
 constexpr int TW_BLK = 256;        // twiddle entries per block
 
 // Hooks of the fused single-launch transform (ntt_fused_fwd_kernel below): a tile body calls them where the
@@ -103,6 +120,9 @@ __device__ __forceinline__ void col_tile_fwd(u64 *sdata, const LimbJob &jb, cons
   const uint32_t offA = (slow << 8) + col, offB = (khB << 12) + colB;     // 32-bit lane offsets
   u64 v[16];
   constexpr int BIN = FIRST ? FWD_IN : FWD_MID;
+#if ALOHA_SETPRIO
+  __builtin_amdgcn_s_setprio(3);        // (experiment) waves that are about to issue their loads go first
+#endif
 #pragma unroll
 #if ALOHA_ABLATE == 2
   for (int kk = 0; kk < 16; kk++) v[kk] = (u64)offA * (kk + 3) + q;
@@ -116,20 +136,28 @@ __device__ __forceinline__ void col_tile_fwd(u64 *sdata, const LimbJob &jb, cons
   for (int ss = 0; ss < 4; ss++)
 #pragma unroll
     for (int g = 0; g < (1 << ss); g++) {
+      if (ALOHA_COL5 && (1 << ss) - 1 + g >= 7) continue;
       const gtw_t p = (gtw_t)blk + (16 << ss) + (khB << ss) + g;
       twb[(1 << ss) - 1 + g].w = p->w;
       twb[(1 << ss) - 1 + g].wp = p->wp;
     }
+#if ALOHA_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   hook.after_loads();
   fwd_radix16<true, BIN>(v, TwStepA{blk}, q, nq);
 #pragma unroll
-  for (int kk = 0; kk < 16; kk++) sdata[col * PITCH + slow + 16 * kk] = v[kk];
+  for (int kk = 0; kk < 16; kk++) sdata[col * PITCH + ((slow + 16 * kk) ^ cswz(col))] = v[kk];
   hook.before_barrier();
   __syncthreads();
   hook.after_barrier();
 #pragma unroll
-  for (int jj = 0; jj < 16; jj++) v[jj] = sdata[colB * PITCH + 16 * khB + jj];
+  for (int jj = 0; jj < 16; jj++) v[jj] = sdata[colB * PITCH + ((16 * khB + jj) ^ cswz(colB))];
+#if ALOHA_COL5
+  fwd_radix16<false, bound_after4(BIN)>(v, TwStepMixT<7>{twb, blk, (int)khB}, q, nq);
+#else
   fwd_radix16<false, bound_after4(BIN)>(v, TwStepReg{twb}, q, nq);
+#endif
   if (HANDOFF) {
     const __amdgpu_buffer_rsrc_t rs = limb_rsrc(jb.dst);
     const uint32_t off0 = (((16 * khB + (rho & 1)) << 8) + cg * 16 + 2 * (pos & 7)) * 8;
@@ -158,7 +186,11 @@ __device__ __forceinline__ void col_tile_fwd(u64 *sdata, const LimbJob &jb, cons
 }
 
 template <bool INV, bool FIRST, bool LAST, bool SC = false>     // SC: jobs may carry their own last-stage scalar (LimbJob::sc)
-__global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict__ jobs,
+__global__ __launch_bounds__(256)
+#if ALOHA_COL5
+__attribute__((amdgpu_waves_per_eu(INV ? 4 : 5, 5)))
+#endif
+void ntt_col_kernel(const LimbJob *__restrict__ jobs,
                                                       const PrimeDev *__restrict__ primes, uint32_t count) {
   __shared__ u64 sdata[LINES * PITCH];
   const int tid = threadIdx.x;
@@ -199,10 +231,10 @@ __global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict_
     for (int jj = 0; jj < 16; jj++) v[jj] = ld_stream(&(src + ((size_t)jj << 8))[offB]);
     inv_radix16<false, FIRST ? INV_IN : INV_MID, false>(v, TwStepMixHi<ALOHA_INV_PRELOAD>{twb, blk, (int)slow}, q, nq);
 #pragma unroll
-    for (int jj = 0; jj < 16; jj++) sdata[col * PITCH + 16 * slow + jj] = v[jj];
+    for (int jj = 0; jj < 16; jj++) sdata[col * PITCH + ((16 * slow + jj) ^ cswz(col))] = v[jj];
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) v[kk] = sdata[col * PITCH + slow + 16 * kk];
+    for (int kk = 0; kk < 16; kk++) v[kk] = sdata[col * PITCH + ((slow + 16 * kk) ^ cswz(col))];
     const LastScale ls = last_scale<LAST && SC>(&jobs[limb], pr);
     inv_radix16<true, INV_MID, LAST>(v, TwStepA{blk}, q, nq, ls.w, ls.ni, ls.nip);
 #pragma unroll
@@ -361,11 +393,17 @@ __device__ __forceinline__ void row_tile(u64 *lds, const LimbJob *__restrict__ j
   const uint32_t ldsA = lwA * RP + plA, ldsB = lwB * RP + 17 * khB;
 
   u64 v[16];
+#if ALOHA_SETPRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
 #pragma unroll
 #if ALOHA_ABLATE == 2
   for (int kk = 0; kk < 16; kk++) v[kk] = (u64)ldsA * (kk + 3) + q;
 #else
   for (int kk = 0; kk < 16; kk++) v[kk] = HANDOFF ? ld_handoff(&src[16 * kk]) : ld_stream(&src[16 * kk]);
+#endif
+#if ALOHA_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
 #endif
   if (!INV) {
     constexpr int BIN = FIRST ? FWD_IN : FWD_MID;
