@@ -442,6 +442,10 @@ struct Rccl {
   int (*CommInitRank)(void **, int, RcclUid, int) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
@@ -460,6 +464,10 @@ Rccl &rccl() {
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
   r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+  r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
+  r.Recv = (decltype(r.Recv))dlsym(r.lib, "ncclRecv");
+  r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
   r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
   return r;
 }
@@ -474,6 +482,7 @@ struct aloha_ks {
   bool resident = false;
   void *comm = nullptr;
   bool own_comm = false;
+  bool p2p = false;                // exchanges as world-1 direct sends + receives per rank (one RCCL group) instead of ncclAllGather
   uint64_t bytes_sent = 0, bytes_received = 0;
   std::string many_key;            // (steps, regions) the "many*" programs were generated for
   std::string err;
@@ -537,8 +546,24 @@ aloha_status all_gather(aloha_ks *ks, uint64_t row0, uint64_t chunk) {
   if (!r.ok) return ks_fail(ks, ALOHA_ERR_DEVICE, "librccl could not be loaded");
   char *base = (char *)aloha_vp_device_ptr(ks->vp, ALOHA_SPACE_SPM, row0);
   if (!base) return ks_fail(ks, ALOHA_ERR_ADDR, "gather buffer outside the SPM space");
-  const int rc = r.AllGather(base + (size_t)lo.rank * chunk * 8, base, (size_t)chunk, kNcclUint64, ks->comm, (hipStream_t)aloha_vp_stream(ks->vp));
-  if (rc) return ks_fail(ks, ALOHA_ERR_DEVICE, "ncclAllGather: %s", r.GetErrorString ? r.GetErrorString(rc) : "error");
+  hipStream_t st = (hipStream_t)aloha_vp_stream(ks->vp);
+  int rc = 0;
+  if (ks->p2p && lo.world > 1 && r.Send && r.Recv && r.GroupStart && r.GroupEnd) {
+    // every GPU pair of an MI355X node has its own xGMI link: world-1 direct sends per rank put 1/(world-1) of the traffic
+    // on every link at once, where a ring all-gather moves each chunk over world-1 hops of one link each;
+    // staggered so that no two ranks start on the same peer
+    rc = r.GroupStart();
+    for (uint32_t d = 1; d < lo.world && !rc; d++) {
+      const uint32_t to = (lo.rank + d) % lo.world, from = (lo.rank + lo.world - d) % lo.world;
+      rc = r.Send(base + (size_t)lo.rank * chunk * 8, (size_t)chunk, kNcclUint64, (int)to, ks->comm, st);
+      if (!rc) rc = r.Recv(base + (size_t)from * chunk * 8, (size_t)chunk, kNcclUint64, (int)from, ks->comm, st);
+    }
+    const int rc2 = r.GroupEnd();
+    if (!rc) rc = rc2;
+  } else {
+    rc = r.AllGather(base + (size_t)lo.rank * chunk * 8, base, (size_t)chunk, kNcclUint64, ks->comm, st);
+  }
+  if (rc) return ks_fail(ks, ALOHA_ERR_DEVICE, "%s: %s", ks->p2p ? "ncclSend/ncclRecv group" : "ncclAllGather", r.GetErrorString ? r.GetErrorString(rc) : "error");
   ks->bytes_sent += (uint64_t)(lo.world - 1) * chunk * 8;
   ks->bytes_received += (uint64_t)(lo.world - 1) * chunk * 8;
   return ALOHA_OK;
@@ -655,6 +680,12 @@ aloha_status aloha_ks_comm_init(aloha_ks *ks, const void *id128) {
   if (prev >= 0) (void)hipSetDevice(prev);
   if (rc) return ks_fail(ks, ALOHA_ERR_DEVICE, "ncclCommInitRank: %s", r.GetErrorString ? r.GetErrorString(rc) : "error");
   ks->comm = comm; ks->own_comm = true;
+  return ALOHA_OK;
+}
+
+aloha_status aloha_ks_set_pairwise(aloha_ks *ks, int on) {
+  if (!ks) return ALOHA_ERR_ARG;
+  ks->p2p = on != 0;
   return ALOHA_OK;
 }
 

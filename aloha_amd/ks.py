@@ -27,7 +27,7 @@ class _KsInfo(C.Structure):
 
 
 EXPORTS = ["aloha_ks_rows_needed", "aloha_ks_create", "aloha_ks_destroy", "aloha_ks_last_error", "aloha_ks_info", "aloha_ks_owned",
-           "aloha_ks_program", "aloha_ks_nccl_unique_id", "aloha_ks_comm_init", "aloha_ks_set_comm", "aloha_ks_load_key",
+           "aloha_ks_program", "aloha_ks_nccl_unique_id", "aloha_ks_comm_init", "aloha_ks_set_comm", "aloha_ks_set_pairwise", "aloha_ks_load_key",
            "aloha_ks_load_ct", "aloha_ks_read_out", "aloha_ks_rotate", "aloha_ks_multiply", "aloha_ks_load_key_hoisted", "aloha_ks_hoist",
            "aloha_ks_rotate_hoisted", "aloha_ks_rotate_hoisted_many", "aloha_ks_rescale", "aloha_vp_stream", "aloha_vp_device"]
 PHASES = ("rot1", "mul1", "mid", "terms", "fin_rot", "fin_mul", "hoist1", "modup", "inner_h", "fin_h", "rescale1", "rescale2")
@@ -49,6 +49,7 @@ def _lib():
         L.aloha_ks_nccl_unique_id.restype = i; L.aloha_ks_nccl_unique_id.argtypes = [p]
         L.aloha_ks_comm_init.restype = i; L.aloha_ks_comm_init.argtypes = [p, p]
         L.aloha_ks_set_comm.restype = i; L.aloha_ks_set_comm.argtypes = [p, p]
+        L.aloha_ks_set_pairwise.restype = i; L.aloha_ks_set_pairwise.argtypes = [p, i]
         L.aloha_ks_load_key.restype = i; L.aloha_ks_load_key.argtypes = [p, p]
         L.aloha_ks_load_ct.restype = i; L.aloha_ks_load_ct.argtypes = [p, i, u32, p]
         L.aloha_ks_read_out.restype = i; L.aloha_ks_read_out.argtypes = [p, u32, p]
@@ -149,6 +150,9 @@ class KeySwitch:
 
     def comm_init(self, unique_id: bytes) -> None:
         self._chk(self._L.aloha_ks_comm_init(self._h, C.create_string_buffer(unique_id, 128)))
+
+    def set_p2p(self, on: bool = True) -> None:
+        self._chk(self._L.aloha_ks_set_pairwise(self._h, int(on)))
 
     def load_key(self, key_full) -> None:
         k = np.ascontiguousarray(key_full, dtype=np.uint64)

@@ -190,6 +190,9 @@ aloha_status aloha_ks_program(const aloha_ks *ks, const char *phase, uint32_t in
 aloha_status aloha_ks_nccl_unique_id(void *id128);
 aloha_status aloha_ks_comm_init(aloha_ks *ks, const void *id128);
 aloha_status aloha_ks_set_comm(aloha_ks *ks, void *nccl_comm);
+/* exchanges as world-1 direct ncclSend/ncclRecv pairs per rank in one group (one per xGMI link) instead of ncclAllGather;
+ * same words either way */
+aloha_status aloha_ks_set_pairwise(aloha_ks *ks, int on);
 aloha_status aloha_ks_load_key(aloha_ks *ks, const uint64_t *key_full);
 aloha_status aloha_ks_load_ct(aloha_ks *ks, int which /* 0: the ciphertext, 1: the second factor of multiply */, uint32_t slot,
                               const uint64_t *ct_full);
