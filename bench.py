@@ -479,8 +479,9 @@ def main() -> int:
                             "bound_ntt_per_s": valu_bound, "frac_of_valu_bound": (B / dev_s_step) / valu_bound,
                             "as_frac_of_hbm_roofline": valu_bound / hbm_bound_ntt_s}
             roof["hbm_bound_ntt_per_s"] = hbm_bound_ntt_s
+            roof["peak_is"] = "hbm"                          # achieved / peak / frac / traffic are the HBM roofline's whatever binds
             if valu_bound < hbm_bound_ntt_s:
-                roof["bound"] = "valu"
+                roof["bound"] = "valu"                       # the tighter bound ("measure and print both")
         pm = pmc_summary()
         if pm.get("commit"):
             roof["traffic_commit"] = pm["commit"]
