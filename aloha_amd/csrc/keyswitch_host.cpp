@@ -53,6 +53,7 @@ inline Ins i_break() { return enc(0x10, 0, 0, 0, 2, 0); }
 inline Ins i_vle(uint32_t vd, uint64_t ptr, uint64_t off) { return enc(0x03, vd, 0, 0, 1, (ptr << 48) | off); }
 inline Ins i_vse(uint32_t vs1, uint64_t ptr, uint64_t off) { return enc(0x07, 0, vs1, 0, 1, (ptr << 48) | off); }
 inline Ins i_vautn(uint32_t vd, uint32_t vs1, uint64_t imm) { return enc(0x1d, vd, vs1, 0, 1, imm); }
+inline Ins i_vaut(uint32_t vd, uint32_t vs1, uint64_t imm) { return enc(0x15, vd, vs1, 0, 1, imm); }
 inline Ins i_vntt(uint32_t vd, uint32_t vs1) { return enc(0x02, vd, vs1, 0, 0, 0); }
 inline Ins i_vintt(uint32_t vd, uint32_t vs1) { return enc(0x06, vd, vs1, 0, 0, 0); }
 inline Ins i_mul_vv(uint32_t vd, uint32_t a, uint32_t b) { return enc(0x01, vd, a, b, 0, 0); }
@@ -165,7 +166,7 @@ void scalar_sum(Block &b, const std::vector<uint64_t> &srcs, const std::vector<u
   b.push_back(i_vse(6, kPtrAbs, dst));
 }
 
-enum Mode { ROTATE, MULTIPLY, HOIST };
+enum Mode { ROTATE, MULTIPLY, HOIST, ROTATE_REF };
 
 // ciphertext slots a loop covers: all `B` of them, or the first `nb` only (hoist_one: slot 0 is the decomposed
 // ciphertext, the other slots serve as rotation slots)
@@ -173,6 +174,38 @@ struct Slots { uint32_t nb; };
 
 std::vector<Block> blocks_phase1(const Layout &lo, Mode mode, Slots sl) {
   std::vector<Block> bl;
+  if (mode == ROTATE_REF) {
+    // alpha = 1: phase 1 exactly as the reference writes it (keyswitch.mem:4-7,:24-27,:100-121): inverse transforms, vaut in
+    // the coefficient domain, the rotated c0 (and the digit under its own modulus) back to NTT form -- a flipped zero then
+    // reaches the basis extension as q_d, as in the RTL (vxu_lane.sv:598)
+    for (uint32_t i = 0; i < lo.Lr; i++)
+      for (uint32_t bi = 0; bi < sl.nb; bi++) {
+        Block b;
+        setq(b, lo.moduli[lo.owned_ct[i]]);
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(0, i, bi)))); b.push_back(i_vintt(2, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_s1(0, i, bi))));
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_in(1, i, bi)))); b.push_back(i_vintt(2, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_s1(1, i, bi))));
+        bl.push_back(std::move(b));
+      }
+    for (uint32_t i = 0; i < lo.Lr; i++)
+      for (uint32_t bi = 0; bi < sl.nb; bi++) {
+        const uint32_t j = lo.owned_ct[i];
+        Block b;
+        setq(b, lo.moduli[j]);
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_s1(1, i, bi)))); b.push_back(i_vaut(2, 0, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.y_slot(j, bi))));
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_s1(0, i, bi)))); b.push_back(i_vaut(2, 0, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_s2(0, i, bi))));
+        bl.push_back(std::move(b));
+      }
+    for (uint32_t i = 0; i < lo.Lr; i++)
+      for (uint32_t bi = 0; bi < sl.nb; bi++) {
+        const uint32_t j = lo.owned_ct[i];
+        Block b;
+        setq(b, lo.moduli[j]);
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.s_s2(0, i, bi)))); b.push_back(i_vntt(2, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_rot(i, bi))));
+        b.push_back(i_vle(0, kPtrAbs, lo.off(lo.y_slot(j, bi)))); b.push_back(i_vntt(2, 0)); b.push_back(i_vse(2, kPtrAbs, lo.off(lo.s_x(i, bi))));
+        bl.push_back(std::move(b));
+      }
+    return bl;
+  }
   if (mode != HOIST)
     for (uint32_t i = 0; i < lo.Lr; i++) {
       const uint32_t j = lo.owned_ct[i];
@@ -609,7 +642,9 @@ aloha_status aloha_ks_create(aloha_vp *vp, const aloha_ks_config *cfg, aloha_ks 
     ks->progs[name] = std::move(p);
   };
   const Slots all{lo.B};
-  add("rot1", lo.Lr, blocks_phase1(lo, ROTATE, all));
+  const bool ref1 = (cfg->flags & ALOHA_KS_REFERENCE_PHASE1) != 0;
+  if (ref1 && lo.alpha != 1) { delete ks; return ALOHA_ERR_ARG; }
+  add("rot1", lo.Lr, blocks_phase1(lo, ref1 ? ROTATE_REF : ROTATE, all));
   add("mul1", lo.Lr, blocks_phase1(lo, MULTIPLY, all));
   {
     std::vector<Block> mid = blocks_modup(lo, all), inner = blocks_inner(lo, false, nullptr);

@@ -215,6 +215,28 @@ def blocks_phase1(lo: HybridLayout, mode: str, bs=None) -> List[List[str]]:
                     f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(1, i, bi)):#x}", "vfqmul.vv v6, v0, v1",
                     f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(0, i, bi)):#x}", "vfqmul.vv v3, v0, v1",
                     "vfqadd.vv v6, v6, v3", f"vse v6, abs+{o(lo.s_base1(i, bi)):#x}"])
+    if mode == "rotate_ref":
+        # alpha = 1 only: phase 1 exactly as the reference writes it (keyswitch.mem:4-7,:24-27,:100-121) -- inverse
+        # transforms, vaut in the coefficient domain, the rotated c0 back to NTT form -- so that a flipped zero reaches
+        # the basis extension as q_d, as in the RTL (vxu_lane.sv:598).  X (the digit under its own modulus) is the
+        # NTT of the rotated c1, word for word what vautn gives.
+        assert lo.alpha == 1
+        for i, j in own:
+            for bi in B:
+                b.append(_setq(lo.moduli[j]) + [
+                    f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", "vintt v2, v0", f"vse v2, abs+{o(lo.s_s1(0, i, bi)):#x}",
+                    f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", "vintt v2, v0", f"vse v2, abs+{o(lo.s_s1(1, i, bi)):#x}"])
+        for i, j in own:
+            for bi in B:
+                b.append(_setq(lo.moduli[j]) + [
+                    f"vle v0, abs+{o(lo.s_s1(1, i, bi)):#x}", "vaut v2, v0, 0x0", f"vse v2, abs+{o(lo.y_slot(j, bi)):#x}",
+                    f"vle v0, abs+{o(lo.s_s1(0, i, bi)):#x}", "vaut v2, v0, 0x0", f"vse v2, abs+{o(lo.s_s2(0, i, bi)):#x}"])
+        for i, j in own:
+            for bi in B:
+                b.append(_setq(lo.moduli[j]) + [
+                    f"vle v0, abs+{o(lo.s_s2(0, i, bi)):#x}", "vntt v2, v0", f"vse v2, abs+{o(lo.s_rot(i, bi)):#x}",
+                    f"vle v0, abs+{o(lo.y_slot(j, bi)):#x}", "vntt v2, v0", f"vse v2, abs+{o(lo.s_x(i, bi)):#x}"])
+        return b
     x_of = (lambda i, bi: lo.s_in(1, i, bi)) if mode == "hoist" else lo.s_x    # hoisted: c1 itself, not rotated
     for i, j in own:                                            # coefficient form, times (Q_d/q_j)^-1 mod q_j: one scaled
         q = lo.moduli[j]                                        # inverse transform per limb (the engine folds the scalar
@@ -382,13 +404,16 @@ class HybridKeySwitch:
     """Rotate / multiply with the hybrid key-switch on one rank of ``world``; ``batch`` ciphertexts per call."""
 
     def __init__(self, vp, n: int, moduli: Sequence[int], specials: Sequence[int], alpha: int, world: int = 1, rank: int = 0,
-                 exchange: Optional[Exchange] = None, base_row: int = 0, batch: int = 1):
+                 exchange: Optional[Exchange] = None, base_row: int = 0, batch: int = 1, reference_phase1: bool = False):
+        """``reference_phase1`` (alpha = 1 only): ``rotate`` runs the reference's own phase 1 (iNTT, ``vaut``, NTT) instead of
+        the NTT-domain automorphism: identical words except where iNTT(c1) has a zero at a sign-flipped position, which the
+        reference lifts as q_d (see ``keyswitch.program_digits``)."""
         self.vp = vp
         self.lo = lo = HybridLayout(n, moduli, specials, alpha, world, rank, base_row, batch)
         self.ex = exchange or Exchange()
         asm = lambda progs: [isa.assemble("\n".join(p)) for p in progs]
         self._p = {
-            "rot1": asm(_pack(blocks_phase1(lo, "rotate"), n)) if lo.Lr else [],
+            "rot1": asm(_pack(blocks_phase1(lo, "rotate_ref" if reference_phase1 else "rotate"), n)) if lo.Lr else [],
             "mul1": asm(_pack(blocks_phase1(lo, "multiply"), n)) if lo.Lr else [],
             "mid": asm(_pack(blocks_modup(lo) + blocks_inner(lo), n)) if lo.Mr else [],
             "terms": asm(_pack(blocks_moddown_terms(lo), n)) if lo.owned_sp else [],

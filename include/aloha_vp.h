@@ -162,11 +162,15 @@ typedef struct {
   uint32_t L, K, alpha;      /* ciphertext primes, special primes, primes per digit                   */
   uint32_t world, rank;      /* ranks sharing the limbs, this rank                                    */
   uint32_t batch;            /* ciphertexts switched per call under the one key (slots 0 .. batch-1)  */
-  uint32_t reserved;
+  uint32_t flags;            /* ALOHA_KS_*                                                            */
   const uint64_t *moduli;    /* L primes                                                              */
   const uint64_t *specials;  /* K primes                                                              */
   uint64_t base_row;         /* first SPM row the handle may use                                      */
 } aloha_ks_config;
+/* alpha = 1 only: aloha_ks_rotate runs the reference's own phase 1 -- iNTT, vaut in the coefficient domain, NTT
+ * (keyswitch.mem:4-7,:24-27,:100-121) -- instead of the NTT-domain automorphism.  Same words, except that a zero coefficient
+ * of iNTT(c1) at a sign-flipped position is lifted as q_d (what the RTL's vaut stores, vxu_lane.sv:598), not as 0. */
+#define ALOHA_KS_REFERENCE_PHASE1 1u
 typedef struct {
   uint32_t dnum, owned_ct, owned_all, rows_per_limb, resident, pad;
   uint64_t spm_rows, ksk_rows;           /* what the aloha_vp must provide (ksk_rows: ONE key region)  */

@@ -39,6 +39,7 @@ int main(int argc, char **argv) {
   aloha_ks_config kc;
   memset(&kc, 0, sizeof kc);
   kc.log_n = 13; kc.L = 2; kc.K = 1; kc.alpha = 1; kc.world = 1; kc.rank = 0; kc.batch = 1; kc.moduli = q; kc.specials = p;
+  kc.flags = ALOHA_KS_REFERENCE_PHASE1;            /* phase 1 as keyswitch.mem writes it (vaut in the coefficient domain) */
   uint64_t spm_rows = 0, ksk_rows = 0;
   CHECK(aloha_ks_rows_needed(&kc, &spm_rows, &ksk_rows));
   aloha_vp_config cfg;
