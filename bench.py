@@ -312,7 +312,7 @@ def keyswitch_child() -> int:
     return 0
 
 
-def keyswitch_in_children(rank: int, timeout_s: float = 300.0):
+def keyswitch_in_children(rank: int, timeout_s: float = 200.0):
     """The sharded key-switch leg runs in CHILD processes with a rendezvous of their own (every rank of this run starts
     one and waits for it with a time limit): its collectives have never met more than one GPU at the time of writing,
     and a failure or a hang there must not cost the headline line -- it becomes {"error": ...} in the `keyswitch` object."""
