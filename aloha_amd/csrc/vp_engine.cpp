@@ -21,6 +21,7 @@
 #include <array>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -103,6 +104,7 @@ struct aloha_vp {
   std::vector<std::unique_ptr<TransformPlan>> plans;
   std::vector<RowsKey> rows_cache;
   std::vector<std::pair<std::vector<uint8_t>, void *>> blobs;   // cached device copies of batched job arrays
+  uint32_t max_slots = kMaxPrimes;   // twiddle sets kept at once (ALOHA_MAX_TWIDDLE_SETS lowers it: tests of the generation reset)
   uint32_t chunk_limbs = 0;      // limbs per chunk of a batched transform (0 = whole batch; chunking did not pay)
   // fused single-launch forward transform at N = 2^16 (ntt_tile.hip): batches of at least fused_min limbs
   uint32_t fused_min = 0, fused_delay = 8, fused_wgs = 0;   // off by default: measured slower than two launches
@@ -233,12 +235,32 @@ bool modulus_ok(uint64_t q) {
 
 ModCtx modctx(uint64_t q) { return ModCtx{q, 0 - q, aloha::nt::barrett_mu(q), (1ull << 59) / ((q >> 32) + 1)}; }
 
-// Twiddle set for (q, N): generated on first use, kept for the life of the handle.
+// The twiddle cache is bounded (max_slots <= kMaxPrimes sets of ~4 MiB at N = 2^16).  Slot indices live inside cached job
+// arrays, plans and recorded runs, so sets are not evicted one by one: an entry point that may need `incoming` new sets
+// and would overflow the cache starts a new GENERATION first -- the stream drains, every set is freed, every cache that
+// could hold a slot index is dropped (the epoch invalidates recorded runs) -- and only then resolves its moduli.
+aloha_status make_room_for_twiddles(aloha_vp *vp, size_t incoming) {
+  if (vp->slots.size() + incoming <= vp->max_slots) return ALOHA_OK;
+  if (incoming > vp->max_slots)
+    return fail(vp, ALOHA_ERR_NOMEM, "one call needs %zu (q, N) twiddle sets, the cache holds %u", incoming, vp->max_slots);
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  for (auto &sl : vp->slots) if (sl.d_tables) (void)hipFree(sl.d_tables);
+  vp->slots.clear();
+  vp->slot_of.clear();
+  vp->plans.clear();
+  vp->rows_cache.clear();
+  vp->run_cache.clear();
+  vp->epoch++;
+  vp->stats.twiddle_generations++;
+  return ALOHA_OK;
+}
+
+// Twiddle set for (q, N): generated on first use, kept until the cache starts a new generation (above).
 aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
   auto key = std::make_pair(q, logn);
   auto it = vp->slot_of.find(key);
   if (it != vp->slot_of.end()) { *out = it->second; return ALOHA_OK; }
-  if (vp->slots.size() >= kMaxPrimes) return fail(vp, ALOHA_ERR_NOMEM, "more than %u (q, N) twiddle sets", kMaxPrimes);
+  if (vp->slots.size() >= vp->max_slots) return fail(vp, ALOHA_ERR_NOMEM, "more than %u (q, N) twiddle sets in one call", vp->max_slots);
   if ((q - 1) % (2ull << logn)) return fail(vp, ALOHA_ERR_ROOT, "q = %#llx is not 1 mod 2N (N = 2^%u)", (u64)q, logn);
   aloha::nt::TwiddleTables tt;
   if (!aloha::nt::make_twiddles(q, logn, &tt)) return fail(vp, ALOHA_ERR_ROOT, "no primitive 2N-th root mod %#llx", (u64)q);
@@ -468,6 +490,7 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   if (const char *e = getenv("ALOHA_NTT_CHUNK")) vp->chunk_limbs = (uint32_t)strtoul(e, nullptr, 10);
   vp->run_cache_on = !getenv("ALOHA_NO_RUN_CACHE");          // (A/B switch: every run goes through the sequencer again)
   vp->graphs_on = getenv("ALOHA_RUN_GRAPH") != nullptr;
+  if (const char *e = getenv("ALOHA_MAX_TWIDDLE_SETS")) vp->max_slots = std::min(kMaxPrimes, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));
   // fused single-launch forward transform (N = 2^16), an experiment kept behind a switch: ALOHA_NTT_FUSED = the smallest
   // batch it serves (unset or 0: never);
   // ALOHA_NTT_FUSED_DELAY = limb groups between a column tile and the row tiles that read it;
@@ -771,6 +794,26 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     if (vp->run_cache.size() >= 1024) { vp->run_cache.clear(); }
     vp->run_cache.emplace(run_hash, std::move(fresh));
   };
+  {
+    // (q, N) pairs this segment may set that have no twiddle set yet: if they would overflow the cache, start a new
+    // generation NOW -- before any job of this run holds a slot index
+    std::set<std::pair<uint64_t, uint64_t>> fresh_sets;
+    uint64_t q_scan = vp->q, vl_scan = vp->vl_bits;
+    for (uint32_t i = pc; i < ALOHA_IRAM_DEPTH; i++) {
+      const uint32_t f6 = (vp->inst[i] >> 26) & 0x3f;
+      if (f6 == 0x10) break;
+      if (f6 == 0x08) q_scan = vp->imm[i];
+      else if (f6 == 0x04) vl_scan = vp->imm[i];
+      else continue;
+      unsigned ln = 0;
+      if (q_scan && vl_logn(vl_scan, vp->max_logn, &ln) == ALOHA_OK && !vp->slot_of.count(std::make_pair(q_scan, ln)))
+        fresh_sets.insert(std::make_pair(q_scan, (uint64_t)ln));
+    }
+    if (vp->slots.size() + fresh_sets.size() > vp->max_slots) {
+      aloha_status s = make_room_for_twiddles(vp, std::min<size_t>(fresh_sets.size(), vp->max_slots));
+      if (s) return s;
+    }
+  }
   const uint64_t epoch0 = vp->epoch;
   const u64 *alias[ALOHA_NVREG] = {nullptr};                // non-null: the register's value is memory at this address
   // Pending batch: deferred memory-to-memory jobs of ONE kind, launched together by flush().
@@ -1371,6 +1414,13 @@ aloha_status aloha_vp_ntt_rows(aloha_vp *vp, int space, uint64_t dst_row, uint64
     if (k.space == space && k.dst_row == dst_row && k.src_row == src_row && k.log_n == log_n && k.count == count &&
         memcmp(k.moduli.data(), moduli, (size_t)count * 8) == 0)
       return run_transforms(vp, k.jobs, log_n, inverse != 0);
+  {
+    std::set<uint64_t> fresh;
+    for (uint32_t i = 0; i < count; i++)
+      if ((i == 0 || moduli[i] != moduli[i - 1]) && !vp->slot_of.count(std::make_pair(moduli[i], (unsigned)log_n))) fresh.insert(moduli[i]);
+    aloha_status s = make_room_for_twiddles(vp, fresh.size());
+    if (s) return s;
+  }
   std::vector<LimbJob> jobs(count);
   uint64_t last_q = 0;
   uint32_t last_slot = 0;

@@ -231,6 +231,7 @@ typedef struct {
   uint64_t twiddle_builds;  /* (q, N) twiddle tables generated                               */
   uint64_t fused_launches;  /* of kernel_launches: N = 2^16 forward transforms run as ONE launch (ABI 2) */
   uint64_t graph_launches;  /* aloha_vp_run calls served by one hipGraphLaunch of a recorded run (ABI 2) */
+  uint64_t twiddle_generations; /* times the bounded twiddle cache was emptied to make room (ABI 2)     */
 } aloha_vp_stats;
 aloha_status aloha_vp_get_stats(const aloha_vp *vp, aloha_vp_stats *out);
 /* copy a vector register to the host (debug; not architecturally visible in the reference) */

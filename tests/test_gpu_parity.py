@@ -859,3 +859,41 @@ def test_more_than_65535_limbs_in_one_batch():
             assert np.array_equal(got[i], oracle.ntt(data[i], q)), i
         vp.ntt_rows(SPM, 0, 0, logn, [q] * count, inverse=True)
         assert np.array_equal(vp.read(SPM, 0, count * n).reshape(count, n), data)
+
+
+def test_twiddle_cache_generations(monkeypatch):
+    """The twiddle cache is bounded; a call that would overflow it empties it first (a new generation: plans, argument
+    caches and recorded runs go with it).  With room for 3 sets: transforms under 7 primes in turn, batches that need 2
+    and 3 new sets at once, a program run again after its sets were dropped -- every result equals the oracle's -- and a
+    batch needing more sets than the cache holds is refused."""
+    monkeypatch.setenv("ALOHA_MAX_TWIDDLE_SETS", "3")
+    logn, n = 12, 1 << 12
+    primes = [oracle.nth_prime(logn, i) for i in range(7)]
+    rng = np.random.default_rng(12)
+    with avp.VP(spm_rows=8 * n // 128, ksk_rows=1, max_log_n=logn) as vp:
+        def check(mods):
+            data = np.stack([residues(rng, n, q) for q in mods])
+            vp.write(SPM, 0, data.reshape(-1))
+            vp.ntt_rows(SPM, 0, 0, logn, mods)
+            got = vp.read(SPM, 0, len(mods) * n).reshape(len(mods), n)
+            for i, q in enumerate(mods):
+                assert np.array_equal(got[i], oracle.ntt(data[i], q)), (mods, i)
+        for q in primes:
+            check([q])
+        check([primes[0], primes[0], primes[5]])
+        check([primes[1], primes[2], primes[3]])
+        check([primes[1], primes[2], primes[3]])                # cached arguments of the current generation
+        assert vp.stats()["twiddle_generations"] >= 3
+        with pytest.raises(avp.AlohaError):
+            check(primes[:4])                                    # four sets at once do not fit three slots
+        # a program (two moduli) recorded, its sets dropped by other work, run again
+        words = isa.assemble("\n".join([f"vsetvl {64 * n:#x}", f"vsetq {primes[0]:#x}", "vle v0, src0+0x0", "vntt v2, v0", "vse v2, rslt+0x0",
+                                         f"vsetq {primes[1]:#x}", f"vle v0, src0+{8 * n:#x}", "vntt v2, v0", f"vse v2, rslt+{8 * n:#x}", "break"]))
+        vp.load_isram(0, words)
+        a = np.stack([residues(rng, n, primes[0]), residues(rng, n, primes[1])])
+        for rep in range(3):
+            vp.write(SPM, 0, a.reshape(-1))
+            assert vp.run(0, src0=0, rslt=2 * n // 128) == 0
+            got = vp.read(SPM, 2 * n // 128, 2 * n).reshape(2, n)
+            assert np.array_equal(got[0], oracle.ntt(a[0], primes[0])) and np.array_equal(got[1], oracle.ntt(a[1], primes[1]))
+            check([primes[4], primes[5], primes[6]])             # evicts the program's two sets
