@@ -808,6 +808,27 @@ aloha_status aloha_ks_multiply(aloha_ks *ks) {
   return key_switch(ks, "mul1", "fin_mul", 0);
 }
 
+/* For hosts that carry the two exchanges themselves (MPI, sockets, a test harness with gloo): the key-switch stage by
+ * stage.  stage 0 = phase 1; [all-gather of buffer 0]; stage 1 = ModUp, inner products, mod-down terms; [all-gather of
+ * buffer 1]; stage 2 = finish.  A gather buffer is world chunks of chunk_words words back to back from SPM row row0; rank
+ * r owns chunk r and must receive the others before the next stage. */
+aloha_status aloha_ks_stage(aloha_ks *ks, int op, int stage, uint64_t k) {
+  if (!ks || !ks->vp || (op != 0 && op != 1) || stage < 0 || stage > 2) return ALOHA_ERR_ARG;
+  if (stage == 0) return run_phase(ks, op ? "mul1" : "rot1", op ? 0 : k);
+  if (stage == 2) return run_phase(ks, op ? "fin_mul" : "fin_rot", 0);
+  aloha_status s = run_phase(ks, "mid", 0);
+  if (!s) s = run_phase(ks, "terms", 0);
+  return s;
+}
+
+aloha_status aloha_ks_gather_buffer(const aloha_ks *ks, int which, uint64_t *row0, uint64_t *chunk_words) {
+  if (!ks || (which != 0 && which != 1) || !row0 || !chunk_words) return ALOHA_ERR_ARG;
+  const Layout &lo = ks->lo;
+  *row0 = lo.row(which ? lo.w : lo.y);
+  *chunk_words = (uint64_t)(which ? lo.Wr : lo.Yr) * lo.B * lo.n;
+  return ALOHA_OK;
+}
+
 /* ---- hoisted rotations: one decomposition of the ciphertext, many rotation steps (hybrid.py: hoist / rotate_hoisted /
  * rotate_hoisted_many; BASELINE config 5 is a BATCH of rotations) -------------------------------------------------- */
 aloha_status aloha_ks_load_key_hoisted(aloha_ks *ks, const uint64_t *key_full, uint64_t k, uint32_t index) {

@@ -29,7 +29,7 @@ class _KsInfo(C.Structure):
 EXPORTS = ["aloha_ks_rows_needed", "aloha_ks_create", "aloha_ks_destroy", "aloha_ks_last_error", "aloha_ks_info", "aloha_ks_owned",
            "aloha_ks_program", "aloha_ks_nccl_unique_id", "aloha_ks_comm_init", "aloha_ks_set_comm", "aloha_ks_set_pairwise", "aloha_ks_load_key",
            "aloha_ks_load_ct", "aloha_ks_read_out", "aloha_ks_rotate", "aloha_ks_multiply", "aloha_ks_load_key_hoisted", "aloha_ks_hoist",
-           "aloha_ks_rotate_hoisted", "aloha_ks_rotate_hoisted_many", "aloha_ks_rescale", "aloha_vp_stream", "aloha_vp_device"]
+           "aloha_ks_rotate_hoisted", "aloha_ks_rotate_hoisted_many", "aloha_ks_rescale", "aloha_ks_stage", "aloha_ks_gather_buffer", "aloha_vp_stream", "aloha_vp_device"]
 PHASES = ("rot1", "mul1", "mid", "terms", "fin_rot", "fin_mul", "hoist1", "modup", "inner_h", "fin_h", "rescale1", "rescale2")
 _bound = False
 
@@ -60,6 +60,8 @@ def _lib():
         L.aloha_ks_rotate_hoisted.restype = i; L.aloha_ks_rotate_hoisted.argtypes = [p, u64, u32]
         L.aloha_ks_rotate_hoisted_many.restype = i; L.aloha_ks_rotate_hoisted_many.argtypes = [p, p, p, u32]
         L.aloha_ks_rescale.restype = i; L.aloha_ks_rescale.argtypes = [p]
+        L.aloha_ks_stage.restype = i; L.aloha_ks_stage.argtypes = [p, i, i, u64]
+        L.aloha_ks_gather_buffer.restype = i; L.aloha_ks_gather_buffer.argtypes = [p, i, C.POINTER(u64), C.POINTER(u64)]
         L.aloha_vp_stream.restype = p; L.aloha_vp_stream.argtypes = [p]
         L.aloha_vp_device.restype = i; L.aloha_vp_device.argtypes = [p]
         _bound = True
@@ -198,3 +200,13 @@ class KeySwitch:
 
     def rescale(self) -> None:
         self._chk(self._L.aloha_ks_rescale(self._h))
+
+    # -- stage by stage, for hosts that carry the exchanges themselves ------------------------------
+    def stage(self, op: str, stage: int, k: int = 0) -> None:
+        self._chk(self._L.aloha_ks_stage(self._h, {"rotate": 0, "multiply": 1}[op], stage, int(k)))
+
+    def gather_buffer(self, which: int):
+        """(first SPM row, words per rank's chunk) of gather buffer ``which`` (0: digits, 1: mod-down terms)."""
+        r, c = C.c_uint64(), C.c_uint64()
+        self._chk(self._L.aloha_ks_gather_buffer(self._h, which, C.byref(r), C.byref(c)))
+        return int(r.value), int(c.value)

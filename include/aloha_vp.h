@@ -205,6 +205,11 @@ aloha_status aloha_ks_read_out(aloha_ks *ks, uint32_t slot, uint64_t *out);
  * handle's stream like aloha_vp_run */
 aloha_status aloha_ks_rotate(aloha_ks *ks, uint64_t k);
 aloha_status aloha_ks_multiply(aloha_ks *ks);
+/* For hosts that carry the exchanges themselves (MPI, sockets, gloo in a test): the same key-switch stage by stage -- op 0
+ * rotate (by k), 1 multiply; stage 0, then all-gather buffer 0, stage 1, all-gather buffer 1, stage 2.  A buffer is `world`
+ * chunks of chunk_words words from SPM row row0; rank r owns chunk r. */
+aloha_status aloha_ks_stage(aloha_ks *ks, int op, int stage, uint64_t k);
+aloha_status aloha_ks_gather_buffer(const aloha_ks *ks, int which, uint64_t *row0, uint64_t *chunk_words);
 /* Hoisted rotations (BASELINE config 5 is a BATCH of rotations): decompose the ciphertext once -- aloha_ks_hoist; with
  * first_slot_only the other batch slots become ROTATION slots -- then rotate by many steps, each with its own key stored
  * by aloha_ks_load_key_hoisted(key, k, region) in KSK region `region` (regions are key_rows apart; the aloha_vp needs

@@ -228,3 +228,67 @@ def test_c_host_reference_phase1_on_gpu_matches_the_reference_algorithm_at_the_z
         m = manifest()["case0"]                                  # and the golden rotate, of course
         kk.load_ct(load(m["kernel1_ct_before_rotate"]).reshape(4, N)); kk.rotate(k)
         assert np.array_equal(kk.read_out(), load(m["kernel1_ct_after_rotate"]).reshape(2, 2, N))
+
+
+def _c_host_rank(rank, world, port, logn, L, K, alpha, seed, op, k, out_dir):
+    """One rank of a sharded key-switch run by the C host, the two all-gathers carried by gloo between the stages."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1 << logn
+        mods, specials, ct, key = _random(n, L, K, alpha, seed)
+        spm, ksk = ks.rows_needed(logn, mods, specials, alpha, world, rank)
+        with avp.VP(spm_rows=spm, ksk_rows=ksk, max_log_n=logn, device=0) as vp, ks.KeySwitch(vp, logn, mods, specials, alpha, world, rank) as kk:
+            kk.load_key(key.reshape(-1)); kk.load_ct(ct); kk.load_ct_b(ct[::-1].copy())
+
+            def exchange(which):
+                row0, chunk = kk.gather_buffer(which)
+                vp.sync()
+                mine = torch.from_numpy(vp.read(0, row0 + rank * chunk // 128, chunk).view(np.int64).copy())
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                for r, part in enumerate(parts):
+                    if r != rank:
+                        vp.write(0, row0 + r * chunk // 128, part.numpy().view(np.uint64))
+
+            kk.stage(op, 0, k); exchange(0)
+            kk.stage(op, 1); exchange(1)
+            kk.stage(op, 2)
+            np.save(os.path.join(out_dir, f"out{rank}.npy"), kk.read_out())
+            np.save(os.path.join(out_dir, f"own{rank}.npy"), np.array(kk.owned_ct))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,op", [(2, "rotate"), (3, "multiply")])
+def test_c_host_sharded_over_ranks_with_the_exchanges_carried_by_the_host(tmp_path, world, op):
+    """The C host's sharded layout end to end: `world` processes (sharing the one GPU of the box), each running its
+    rank's stages through the C ABI, the digit and mod-down all-gathers carried between the stages by gloo (an RCCL
+    communicator needs one GPU per rank).  L = 5, K = 2, alpha = 2: uneven shards, a special prime on two ranks.  Every
+    rank's owned limbs == the single-rank oracle machine."""
+    import socket
+    import torch.multiprocessing as mp
+    logn, L, K, alpha, seed = 12, 5, 2, 2, 23
+    n = 1 << logn
+    k = pow(3, 5, 2 * n)
+    mods, specials, ct, key = _random(n, L, K, alpha, seed)
+    lo = hybrid.HybridLayout(n, mods, specials, alpha)
+    ref = hybrid.HybridKeySwitch(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows), n, mods, specials, alpha)
+    ref.load_key(key); ref.load_ct(ct); ref.load_ct_b(ct[::-1].copy())
+    ref.rotate(k) if op == "rotate" else ref.multiply()
+    exp = ref.read_out()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_c_host_rank, args=(world, port, logn, L, K, alpha, seed, op, k, str(tmp_path)), nprocs=world, join=True)
+    seen = set()
+    for r in range(world):
+        out, own = np.load(tmp_path / f"out{r}.npy"), np.load(tmp_path / f"own{r}.npy")
+        for i, j in enumerate(own):
+            assert np.array_equal(out[:, i], exp[:, j]), f"rank {r} limb {j}"
+            seen.add(int(j))
+    assert seen == set(range(L))
