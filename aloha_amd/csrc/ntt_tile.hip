@@ -577,6 +577,9 @@ struct FusedHook {
   }
 };
 
+#ifndef ALOHA_FUSED_NOPOLL
+#define ALOHA_FUSED_NOPOLL 0
+#endif
 #ifndef ALOHA_FUSED_EAGER
 #define ALOHA_FUSED_EAGER 0
 #endif
@@ -713,7 +716,11 @@ void ntt_fused_dispatch_kernel(const LimbJob *__restrict__ jobs, const LimbJob *
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(done + limb * kFusedCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
+#if ALOHA_FUSED_NOPOLL       // TIMING EXPERIMENT ONLY (results may be wrong): what would a free readiness check buy?
+    if (false) {
+#else
     if (wave == 0) {
+#endif
       const uint32_t first = tk.y & 0x0fffffffu, nl = 1u << (tk.y >> 28);
       uint32_t spins = 0, ok = 0;
       for (;;) {
@@ -728,8 +735,10 @@ void ntt_fused_dispatch_kernel(const LimbJob *__restrict__ jobs, const LimbJob *
         ok_flag = ok;
       }
     }
+#if !ALOHA_FUSED_NOPOLL
     __syncthreads();
     if (!ok_flag) return;
+#endif
     row_tile<false, true, false, true, true>(sdata + wave * 4 * RP, inplace, primes, tiles[tk.x & 0x7fffffffu], (uint32_t)wave, lane, NoHook{});
   }
 }
@@ -860,8 +869,17 @@ void build_fused_schedule(const std::vector<TileDesc> &uni_tiles, unsigned log_r
     const uint32_t nl = 1u << td.pb_log, ntiles = (1u << log_rows) / (16u >> td.pb_log);
     if (groups.empty() || in_group >= 16) { groups.emplace_back(); in_group = 0; }
     Group &g = groups.back();
-    for (uint32_t l = 0; l < nl; l++)
-      for (uint32_t cg = 0; cg < 16; cg++) g.cols.push_back(((td.first_limb + l) << 4) | cg);
+    // column tickets of a bundle in XCD-affine order where the bundle allows it: positions are dealt round-robin over the 8
+    // XCDs, so limb = 8*half + (k mod 8) puts the 16 column tiles of a limb -- which together cover each 2 KiB row -- on
+    // ONE XCD (as in ntt_col_kernel: 6.05 vs 5.2 TB/s on the bare pattern); smaller bundles keep the plain order
+    if (nl % 8 == 0) {
+      for (uint32_t h = 0; h < nl / 8; h++)
+        for (uint32_t cg = 0; cg < 16; cg++)
+          for (uint32_t l = 0; l < 8; l++) g.cols.push_back(((td.first_limb + 8 * h + l) << 4) | cg);
+    } else {
+      for (uint32_t l = 0; l < nl; l++)
+        for (uint32_t cg = 0; cg < 16; cg++) g.cols.push_back(((td.first_limb + l) << 4) | cg);
+    }
     const uint64_t pollw = (uint64_t)(td.first_limb | ((uint32_t)td.pb_log << 28)) << 32;     // high word: the bundle to poll
     for (uint32_t i = 0; i < ntiles; i++) g.rows.push_back(pollw | 0x80000000u | (uint32_t)(t + i));
     in_group += nl;

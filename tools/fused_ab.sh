@@ -2,6 +2,7 @@
 # A/B of the fused single-launch forward transform against the two-launch form, plus ablation builds
 # (abl1 = no butterflies: memory + scheduling skeleton; abl2 = no global loads/stores: arithmetic + LDS skeleton).
 # usage: tools/fused_ab.sh <tag> ; needs lib variants built by `python -m aloha_amd.build --variant=...`
+export ALOHA_NTT_FUSED=256   # (the fused forms are off by default; "two launches" lines override with 0)
 tag=${1:-r02}
 out=gpurun_out/${tag}_fused_ab.txt
 : > $out

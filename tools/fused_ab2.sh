@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the fused single-launch forward transform (delay sweep, build variants) against the two-launch form.
+export ALOHA_NTT_FUSED=256   # (the fused forms are off by default; "two launches" lines override with 0)
 tag=${1:-r02}
 out=gpurun_out/${tag}_fused_ab.txt
 : > $out

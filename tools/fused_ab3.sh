@@ -1,4 +1,5 @@
 #!/bin/bash
+export ALOHA_NTT_FUSED=256   # (the fused forms are off by default; "two launches" lines override with 0)
 tag=${1:-r02}
 out=gpurun_out/${tag}_fused_ab.txt
 : > $out
