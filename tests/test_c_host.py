@@ -39,3 +39,16 @@ def test_c_program_reproduces_the_golden_rotate(tmp_path):
     p = subprocess.run([exe, GOLDEN, image], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "golden rotate reproduced (C host and reference image)" in p.stdout
+
+
+def test_program_generator_is_clean_under_asan_and_ubsan(tmp_path):
+    """The C host's generator (csrc/keyswitch_host.cpp, numtheory.cpp) compiled with g++ -fsanitize=address,undefined on the
+    CPU: plans for 7 layouts x all ranks, every phase fetched, on-demand programs regenerated (tests/c/ks_plan_sanitize.cpp).
+    (GPU AddressSanitizer is not available on the pool; the host code is what a sanitizer can see.)"""
+    exe = str(tmp_path / "ks_plan_sanitize")
+    cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-Wno-subobject-linkage",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "c", "ks_plan_sanitize.cpp"), "-ldl", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "ks_plan_sanitize ok" in p.stdout and "ERROR" not in p.stderr
