@@ -52,3 +52,17 @@ def test_program_generator_is_clean_under_asan_and_ubsan(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "ks_plan_sanitize ok" in p.stdout and "ERROR" not in p.stderr
+
+
+def test_oracle_is_clean_under_asan_and_ubsan(tmp_path):
+    """The oracle's C restatement under gcc -fsanitize=address,undefined: the golden rotate through its ISA machine with the
+    reference's keyswitch.mem image, transform round trips at N = 2^10 and 2^16, the vautn identity, the RTL Barrett form
+    (tests/c/oracle_sanitize.c).  The checker is code too."""
+    exe = str(tmp_path / "oracle_sanitize")
+    cmd = ["gcc", "-std=gnu99", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fopenmp",
+           os.path.join(ROOT, "tests", "c", "oracle_sanitize.c"), "-lm", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    img = manifest()["isram"]["keyswitch"]
+    p = subprocess.run([exe, GOLDEN, img["file"], str(img["words"])], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "oracle_sanitize ok" in p.stdout and "ERROR" not in p.stderr
