@@ -213,9 +213,13 @@ __global__ __launch_bounds__((1 << LOGN) / 16) __attribute__((amdgpu_waves_per_e
 template <int LOGN, bool INV, bool SC = false>
 hipError_t launch_single(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count) {
   constexpr int N = 1 << LOGN;
-  const void *fn = reinterpret_cast<const void *>(&ntt_single_kernel<LOGN, INV, SC>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, N * 8);
-  if (e != hipSuccess) return e;
+  static bool attr_set = false;       // once per instantiation (and process): the call is not free, the launch path is hot
+  if (!attr_set) {
+    const void *fn = reinterpret_cast<const void *>(&ntt_single_kernel<LOGN, INV, SC>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, N * 8);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
   hipLaunchKernelGGL((ntt_single_kernel<LOGN, INV, SC>), dim3(count), dim3(N / 16), N * 8, st, d_jobs, d_primes);
   return hipGetLastError();
 }
