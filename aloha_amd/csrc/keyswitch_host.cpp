@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -535,11 +536,23 @@ aloha_status ks_fail(aloha_ks *ks, aloha_status s, const char *fmt, ...) {
   return s;
 }
 
+// Every modulus -- ciphertext and special primes alike -- must be what the engine's vsetq accepts (a prime in
+// (2^59, 2^60): vp_engine.cpp modulus_ok), have a 2N-th root of unity, and differ from all the others: the layout's
+// scalars are inverses and products modulo them (a zero modulus would divide by zero, a repeated one has no inverse).
 aloha_status check_config(const aloha_ks_config *c) {
   if (!c || !c->moduli || !c->specials) return ALOHA_ERR_ARG;
   if (c->log_n < 10 || c->log_n > 16) return ALOHA_ERR_VL;
   if (!c->L || !c->K || !c->alpha || !c->world || c->rank >= c->world || !c->batch) return ALOHA_ERR_ARG;
   if (c->L + c->K > 4096 || c->batch > 64) return ALOHA_ERR_ARG;
+  std::vector<uint64_t> all(c->moduli, c->moduli + c->L);
+  all.insert(all.end(), c->specials, c->specials + c->K);
+  for (uint64_t m : all) {
+    if (!(m > (1ull << 59) && m < (1ull << 60)) || !(m & 1) || !aloha::nt::is_prime(m)) return ALOHA_ERR_MODULUS;
+    if ((m - 1) % (2ull << c->log_n)) return ALOHA_ERR_ROOT;
+  }
+  std::sort(all.begin(), all.end());
+  for (size_t i = 1; i < all.size(); i++)
+    if (all[i] == all[i - 1]) return ALOHA_ERR_MODULUS;
   return ALOHA_OK;
 }
 
@@ -635,6 +648,12 @@ aloha_status aloha_ks_create(aloha_vp *vp, const aloha_ks_config *cfg, aloha_ks 
   ks->vp = vp;
   ks->lo = layout_of(cfg);
   const Layout &lo = ks->lo;
+  if (vp) {                                                       // the handle must cover this rank's share of the layout
+    aloha_vp_config have;
+    if (aloha_vp_get_config(vp, &have) != ALOHA_OK) { delete ks; return ALOHA_ERR_ARG; }
+    if (have.max_log_n < cfg->log_n) { delete ks; return ALOHA_ERR_VL; }
+    if (have.spm_rows < lo.spm_rows_needed() || have.ksk_rows < lo.ksk_limbs() * lo.rows) { delete ks; return ALOHA_ERR_ADDR; }
+  }
   bool ok = true;
   auto add = [&](const char *name, bool cond, const std::vector<Block> &bl) {
     std::vector<std::vector<uint32_t>> p;

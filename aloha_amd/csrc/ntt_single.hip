@@ -27,6 +27,8 @@
 // depends on the register index only (scalar loads), afterwards on the thread's upper bits
 // (vector loads, 16 B per lane).  The inverse runs the same steps backwards with the
 // Gentleman-Sande butterflies and fuses N^-1 into the last one.
+#include <atomic>
+
 #include "kernels.hpp"
 #include "modarith.hpp"
 #include "ntt_device.hpp"
@@ -213,12 +215,17 @@ __global__ __launch_bounds__((1 << LOGN) / 16) __attribute__((amdgpu_waves_per_e
 template <int LOGN, bool INV, bool SC = false>
 hipError_t launch_single(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count) {
   constexpr int N = 1 << LOGN;
-  static bool attr_set = false;       // once per instantiation (and process): the call is not free, the launch path is hot
-  if (!attr_set) {
+  // once per instantiation and DEVICE (the attribute is per device, and handles of one process may live on different
+  // devices): the call is not free and the launch path is hot.  A racing second thread at worst sets it twice.
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (dev > 63 || !(attr_set.load(std::memory_order_acquire) & bit)) {
     const void *fn = reinterpret_cast<const void *>(&ntt_single_kernel<LOGN, INV, SC>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, N * 8);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev <= 63) attr_set.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((ntt_single_kernel<LOGN, INV, SC>), dim3(count), dim3(N / 16), N * 8, st, d_jobs, d_primes);
   return hipGetLastError();

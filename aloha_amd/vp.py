@@ -38,7 +38,7 @@ EXPORTS = ["aloha_vp_abi_version", "aloha_status_string", "aloha_vp_create", "al
            "aloha_vp_load_isram", "aloha_vp_load_isram_hex", "aloha_vp_run", "aloha_vp_sync",
            "aloha_vp_ntt_rows", "aloha_find_psi", "aloha_nth_prime", "aloha_vp_get_stats",
            "aloha_vp_peek_vreg", "aloha_vp_encode", "aloha_vp_decode", "aloha_vp_fill_synthetic",
-           "aloha_vp_valu_clock"]
+           "aloha_vp_valu_clock", "aloha_vp_get_config", "aloha_vp_set_scratch"]
 
 
 class AlohaError(RuntimeError):
@@ -99,6 +99,8 @@ def load_library() -> C.CDLL:
     L.aloha_vp_decode.restype = i; L.aloha_vp_decode.argtypes = [p, i, u64, u64, p, u32, u32, u64, C.c_double]
     L.aloha_vp_fill_synthetic.restype = i; L.aloha_vp_fill_synthetic.argtypes = [p, i, u64, u32, p, u32, u64, u64]
     L.aloha_vp_valu_clock.restype = i; L.aloha_vp_valu_clock.argtypes = [p, C.c_double, C.POINTER(C.c_double)]
+    L.aloha_vp_get_config.restype = i; L.aloha_vp_get_config.argtypes = [p, C.POINTER(_Config)]
+    L.aloha_vp_set_scratch.restype = i; L.aloha_vp_set_scratch.argtypes = [p, u64, u64]
     _lib = L
     return L
 
@@ -188,6 +190,17 @@ class VP:
 
     def sync(self) -> None:
         self._chk(self._L.aloha_vp_sync(self._h))
+
+    def set_scratch(self, row: int = 0, nrows: int = 0) -> None:
+        """Declare SPM rows [row, row + nrows) as the caller's scratch: rows of the window that a run writes are
+        undefined once that run has returned (``nrows = 0``: no window, the default)."""
+        self._chk(self._L.aloha_vp_set_scratch(self._h, row, nrows))
+
+    def config(self) -> dict:
+        c = _Config()
+        self._chk(self._L.aloha_vp_get_config(self._h, C.byref(c)))
+        return {"device": int(c.device), "spm_rows": int(c.spm_rows), "ksk_rows": int(c.ksk_rows),
+                "max_log_n": int(c.max_log_n), "flags": int(c.flags)}
 
     # -- batched transforms -------------------------------------------------------------------
     def ntt_rows(self, space: int, dst_row: int, src_row: int, log_n: int, moduli: Sequence[int],

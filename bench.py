@@ -88,7 +88,34 @@ def self_launch(argv, gpus: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    return max(p.wait() for p in procs)
+    # The ranks are polled together: the first one that fails -- a non-zero exit or a death by signal (negative code: a GPU
+    # fault ends a rank with SIGABRT / SIGSEGV) -- ends the run; its siblings, which would otherwise sit in the rendezvous
+    # or in a collective until a timeout, are terminated, and the failure is what this process returns.
+    worst, failed_at = 0, None
+    while procs:
+        for p in list(procs):
+            rc = p.poll()
+            if rc is None:
+                continue
+            procs.remove(p)
+            if rc != 0 and worst == 0:
+                worst = rc if rc > 0 else 128 - rc            # 128 + signal number, as a shell reports it
+                failed_at = time.monotonic()
+        if not procs:
+            break
+        time.sleep(0.05)
+        if failed_at is not None and time.monotonic() - failed_at > 3.0:   # (siblings that fail for the same reason say so themselves first)
+            for o in procs:
+                o.terminate()
+            deadline = time.monotonic() + 10.0                  # a rank that ignores SIGTERM for 10 s is killed
+            while procs and time.monotonic() < deadline:
+                procs = [o for o in procs if o.poll() is None]
+                time.sleep(0.05)
+            for o in procs:
+                o.kill()
+                o.wait()
+            procs = []
+    return worst
 
 
 
@@ -371,6 +398,11 @@ def main() -> int:
     if os.environ.get("ALOHA_BENCH_ECHO"):                       # (tests: shows what a rank was started with)
         print(f"bench.py rank {rank} of {world} local {local_rank} master {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
               file=sys.stderr)
+    if os.environ.get("ALOHA_BENCH_TEST_DIE"):                   # (tests: "<rank>:<signal>" -- that rank dies by the signal, the others wait)
+        r, sig = (int(x) for x in os.environ["ALOHA_BENCH_TEST_DIE"].split(":"))
+        if rank == r:
+            os.kill(os.getpid(), sig)
+        time.sleep(120)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the engine has no CPU path", file=sys.stderr)
         return 2

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define ALOHA_VP_ABI_VERSION 2
+#define ALOHA_VP_ABI_VERSION 3
 
 typedef enum {
   ALOHA_OK = 0,
@@ -87,6 +87,9 @@ void aloha_vp_destroy(aloha_vp *vp);
 const char *aloha_vp_last_error(const aloha_vp *vp);      /* text of the last failure      */
 const char *aloha_status_string(aloha_status s);
 uint32_t aloha_vp_abi_version(void);
+/* the configuration the handle was created with (ABI 3): callers that lay data out in the handle's memories -- the
+ * key-switch host below -- check their needs against it instead of finding out by an address error */
+aloha_status aloha_vp_get_config(const aloha_vp *vp, aloha_vp_config *out);
 
 /* ---- memory (replaces the AXI DMA paths) ------------------------------------------------ */
 aloha_status aloha_vp_write(aloha_vp *vp, int space, uint64_t row, const void *host_src, uint64_t bytes);
@@ -107,6 +110,13 @@ aloha_status aloha_vp_load_isram_hex(aloha_vp *vp, uint32_t base_pc, const char 
 aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
                           uint64_t rslt_row, uint64_t ksk_row, uint64_t rot_step);
 aloha_status aloha_vp_sync(aloha_vp *vp);   /* `done` */
+/* Scratch window (ABI 3; no counterpart in the reference, whose memories are all observable): the caller declares SPM rows
+ * [row, row + nrows) as its own scratch.  Rows of the window that a run WRITES have undefined contents once that run has
+ * returned; everything else -- every byte a `vse` writes outside the window, in program order -- is unchanged.  It lets the
+ * sequencer keep a value that one instruction stores and a later instruction of the SAME run loads in registers (the digit
+ * limbs between their transform and the inner product with the key, keyswitch.mem:46-79).  nrows = 0 clears the window
+ * (the default: none).  The window is part of what a recorded run is keyed on. */
+aloha_status aloha_vp_set_scratch(aloha_vp *vp, uint64_t row, uint64_t nrows);
 
 /* ---- batched transforms on rows (the fused form of N x {vsetq; vle; vntt|vintt; vse}) ---------
  * count limbs of 2^log_n coefficients; limb i is read at src_row + i*(N/128) and written at

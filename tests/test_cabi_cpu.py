@@ -37,7 +37,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_abi_version_and_status_strings(lib):
-    assert lib.aloha_vp_abi_version() == 2
+    assert lib.aloha_vp_abi_version() == 3
     for s in range(12):
         assert lib.aloha_status_string(s)
     assert lib.aloha_status_string(0) == b"ok"
@@ -56,7 +56,7 @@ def test_create_rejects_bad_config(lib):
     h = ctypes.c_void_p()
     cfg = avp._Config(abi_version=99, device=0, spm_rows=1, ksk_rows=1, max_log_n=13, flags=0, stream=None)
     assert lib.aloha_vp_create(ctypes.byref(cfg), ctypes.byref(h)) == avp.ERR_ARG
-    cfg = avp._Config(abi_version=2, device=0, spm_rows=1, ksk_rows=1, max_log_n=17, flags=0, stream=None)
+    cfg = avp._Config(abi_version=3, device=0, spm_rows=1, ksk_rows=1, max_log_n=17, flags=0, stream=None)
     assert lib.aloha_vp_create(ctypes.byref(cfg), ctypes.byref(h)) == avp.ERR_ARG
     assert lib.aloha_vp_create(None, ctypes.byref(h)) == avp.ERR_ARG
 
@@ -101,3 +101,20 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert all(" of 3 " in l and "master 127.0.0.1:" in l for l in lines)
     assert len({l.split("master ")[1] for l in lines}) == 1          # one rendezvous for all ranks
     assert p.stderr.count("bench.py needs a GPU") == 3
+
+
+def test_bench_self_launch_reports_a_rank_killed_by_a_signal():
+    """A rank that dies by a signal (a GPU fault ends a process with SIGABRT) must fail the whole run -- its negative
+    return code may not hide behind a sibling's 0 -- and its siblings must be ended instead of waiting for a timeout."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ALOHA_BENCH_TEST_DIE"] = f"1:{int(signal.SIGABRT)}"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 128 + int(signal.SIGABRT), (p.returncode, p.stderr[-400:])
+    assert time.monotonic() - t0 < 100                             # the sleeping siblings (120 s) were terminated

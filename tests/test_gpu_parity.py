@@ -897,3 +897,13 @@ def test_twiddle_cache_generations(monkeypatch):
             got = vp.read(SPM, 2 * n // 128, 2 * n).reshape(2, n)
             assert np.array_equal(got[0], oracle.ntt(a[0], primes[0])) and np.array_equal(got[1], oracle.ntt(a[1], primes[1]))
             check([primes[4], primes[5], primes[6]])             # evicts the program's two sets
+        # a program that transforms under the modulus it INHERITS (no vsetq of its own) on a full cache: the inherited
+        # (q, N) pair has no set any more and must be counted when deciding whether to start a new generation
+        head = isa.assemble("\n".join([f"vsetvl {64 * n:#x}", f"vsetq {primes[0]:#x}", "break"]))
+        body = isa.assemble("\n".join(["vle v0, src0+0x0", "vntt v2, v0", "vse v2, rslt+0x0", "break"]))
+        vp.load_isram(0, head); vp.load_isram(16, body)
+        assert vp.run(0) == 0                                    # q = primes[0], VL = N; no transform yet
+        check([primes[4], primes[5], primes[6]])                 # the cache is full of other sets
+        vp.write(SPM, 0, a[0])
+        assert vp.run(16, src0=0, rslt=2 * n // 128) == 0, vp.last_error
+        assert np.array_equal(vp.read(SPM, 2 * n // 128, n), oracle.ntt(a[0], primes[0]))
