@@ -17,8 +17,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libaloha_vp.so")
-SOURCES = ["vp_engine.cpp", "keyswitch_host.cpp", "numtheory.cpp", "ew_kernels.hip", "ntt_tile.hip", "ntt_single.hip", "encode_kernels.hip"]
-HEADERS = ["kernels.hpp", "modarith.hpp", "ntt_device.hpp", "numtheory.hpp", os.path.join("..", "..", "include", "aloha_vp.h")]
+SOURCES = ["vp_engine.cpp", "keyswitch_host.cpp", "numtheory.cpp", "ew_kernels.hip", "ntt_tile.hip", "ntt_ks.hip", "ntt_single.hip", "encode_kernels.hip"]
+HEADERS = ["kernels.hpp", "modarith.hpp", "ntt_device.hpp", "ntt_tiles.hpp", "numtheory.hpp", os.path.join("..", "..", "include", "aloha_vp.h")]
+# Variant builds (measured-and-rejected experiments, ablations): the two-pass tile kernels with every knob and
+# the single-launch transforms replace the default tile file, and -DALOHA_EXPERIMENTS enables their switches in the engine
+# (ALOHA_NTT_FUSED*, ALOHA_RUN_GRAPH).  The default library contains none of it.
+VARIANT_SOURCES = [os.path.join("experiments", "ntt_tile_knobs.hip") if s == "ntt_tile.hip" else s for s in SOURCES]
+EXPERIMENTS_LIB = "exp"          # lib/libaloha_vp_exp.so: the plain variant the experiments' tests load (tests/test_experiments.py)
 ARCH = "gfx950"
 
 
@@ -33,13 +38,17 @@ def _newest(paths) -> float:
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build_variant(name: str, defines) -> str:
+def build_variant(name: str, defines=(), force: bool = True) -> str:
     """A/B variant of the library with extra -D macros -> lib/libaloha_vp_<name>.so (select it with
     ALOHA_VP_LIB=...; bench.py then skips its oracle guard, variants may compute garbage on purpose)."""
     out = os.path.join(LIBDIR, f"libaloha_vp_{name}.so")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}"] + [f"-D{d}" for d in defines] + \
-          ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl,-rpath,/opt/rocm/lib", "-ldl"]
+    srcs = [os.path.join(CSRC, s) for s in VARIANT_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest(deps):
+        return out
+    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-DALOHA_EXPERIMENTS=1"] + \
+          [f"-D{d}" for d in defines if d] + ["-o", out] + srcs + ["-Wl,-rpath,/opt/rocm/lib", "-ldl"]
     subprocess.check_call(cmd)
     return out
 
@@ -78,5 +87,5 @@ if __name__ == "__main__":
         if a.startswith("--ablate="):
             print(build_ablation(int(a.split("=")[1])))
         if a.startswith("--variant="):                      # --variant=name:MACRO=1,MACRO2=0
-            name, defs = a.split("=", 1)[1].split(":", 1)
+            name, _, defs = a.split("=", 1)[1].partition(":")
             print(build_variant(name, defs.split(",")))

@@ -114,6 +114,39 @@ struct LimbJob {
   // the extra scalar costs nothing, and the constant is one modular add on the canonical result.
   u64 sc[4];
   u64 addc;
+  // forward transforms of the fused key-switch phases (N = 2^16, ntt_tile.hip / ntt_ks.hip); 0 = none, else index + 1:
+  uint32_t pro;          // SumSrc: the limb to transform is a sum of scaled memory operands, formed in the column pass's loads
+  uint32_t epi;          // RowEpi: the row pass ends in a sum of scaled operands with the transform as one of them
+};
+
+// A limb that exists only as  sum_t a_t * s_t + cst  (mod q): the source of a column pass (LimbJob::pro).
+struct SumSrc {
+  const u64 *a[kSumTerms];
+  u64 s[kSumTerms], sp[kSumTerms];   // scalars (< q) and their Shoup companions
+  u64 cst;                           // constant term (< q)
+  int nterms, pad;                   // 1..kSumTerms
+};
+// Epilogue of a forward row pass (LimbJob::epi):  out = t * s[0] + sum_i a_i * s[i + 1] + cst  (mod q), t = the transform
+// of the limb -- the tail of the mod-down, (acc - t) * P^-1 + base (keyswitch.mem:102-117), without a pass of its own.
+constexpr int kEpiOps = 3;
+struct RowEpi {
+  const u64 *a[kEpiOps];
+  u64 s[kEpiOps + 1], sp[kEpiOps + 1];
+  u64 cst;
+  u64 *out;
+  uint32_t nops;         // operands besides t: 0..kEpiOps
+  uint32_t store_t;      // 1: the transform itself is stored to the job's dst as well
+};
+// One inner product with the key (keyswitch.mem:46-79) fused behind the row pass of its digits:
+//   out_c = sum_d X_d .* KEY_{d,c}   c = 0, 1,   X_d = NTT(x_d) for the first nt digits (x_d: column-pass output, in
+//   place at its dst), X_d = x_d as it stands for the next np digits (already in NTT form).
+constexpr int kRowDotMax = 64;
+struct RowDotGroup {
+  const u64 *x[kRowDotMax];
+  u64 *xout[kRowDotMax];         // transformed digits: where NTT(x_d) is stored, or null (not needed in memory)
+  const u64 *key[kRowDotMax][2];
+  u64 *out[2];
+  uint32_t prime, nt, np, pad;
 };
 struct PrimeDev {
   ModCtx m;
@@ -149,7 +182,18 @@ hipError_t ntt_tile_batch(hipStream_t st, const LimbJob *d_jobs, const LimbJob *
                           unsigned single_max = 13,    // largest log2 N transformed by the single-pass kernels (0: never)
                           bool scaled = false);       // inverse only: some job carries its own last-stage scalar (LimbJob::scaled)
 
-// Fused forward transform for N = 2^16 (ntt_tile.hip, ntt_fused_fwd_kernel): both passes in ONE persistent launch,
+// ---- the fused key-switch phases at N = 2^16 (forward transforms; ntt_tile.hip, ntt_ks.hip) -------------------------
+// column pass of limbs [0, count) of d_jobs; jobs with `pro` take their input from d_sums
+hipError_t ntt_fwd16_cols(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count, const SumSrc *d_sums,
+                          uint64_t *launches);
+// row pass over the tile lists (in place on the jobs' dst); jobs with `epi` end in their epilogue (d_epis)
+hipError_t ntt_fwd16_rows(hipStream_t st, const LimbJob *d_inplace, const PrimeDev *d_primes, const TileDesc *d_uni_tiles, uint32_t n_uni,
+                          const TileDesc *d_glb_tiles, uint32_t n_glb, const RowEpi *d_epis, uint64_t *launches);
+// row pass of every group's transformed digits + inner product with the key, one launch
+hipError_t ntt_fwd16_rowdot(hipStream_t st, const RowDotGroup *d_groups, uint32_t ngroups, const PrimeDev *d_primes, uint64_t *launches);
+
+#ifdef ALOHA_EXPERIMENTS
+// Fused forward transform for N = 2^16 (experiments/ntt_tile_knobs.hip, ntt_fused_fwd_kernel): both passes in ONE persistent launch,
 // the intermediate handed from column tiles to row tiles through the Infinity Cache.  Needs a batch whose row tiles
 // are all bundle tiles (>= 4 limbs per prime adjacent).  d_ctl: fused_ctl_words(count) u32 of device memory (zeroed by
 // the launcher): ticket counters and one arrival counter per limb.  d_status: one sticky u32 owned by the caller,
@@ -164,6 +208,7 @@ uint32_t fused_workgroups_per_cu();      // resident workgroups of the fused ker
 hipError_t ntt_fused_fwd(hipStream_t st, const LimbJob *d_jobs, const LimbJob *d_inplace, const PrimeDev *d_primes,
                          const TileDesc *d_tiles, const uint64_t *d_tickets, uint32_t npos, uint32_t count,
                          uint32_t *d_ctl, uint32_t *d_status, uint32_t workgroups, uint64_t *launches);
+#endif
 
 // Single-pass transforms for N = 2^12 .. 2^14 (the limb stays in one CU's LDS: one read + one write of
 // the limb, ntt_single.hip); d_jobs = the {src, dst} entries of the limbs to transform.

@@ -253,9 +253,11 @@ std::vector<Block> blocks_phase1(const Layout &lo, Mode mode, Slots sl) {
   return bl;
 }
 
-std::vector<Block> blocks_modup(const Layout &lo, Slots sl) {
+// [jl0, jl1): the owned moduli the blocks cover (a phase may be cut into programs by modulus, see mid_programs)
+std::vector<Block> blocks_modup(const Layout &lo, Slots sl, uint32_t jl0 = 0, uint32_t jl1 = ~0u) {
   std::vector<Block> bl;
-  for (uint32_t jl = 0; jl < lo.Mr; jl++) {                       // basis extension sums
+  jl1 = std::min(jl1, lo.Mr);
+  for (uint32_t jl = jl0; jl < jl1; jl++) {                       // basis extension sums
     const uint32_t j = lo.owned_all[jl];
     const uint64_t m = lo.mods_all[j];
     for (uint32_t d = 0; d < lo.dnum; d++) {
@@ -273,7 +275,7 @@ std::vector<Block> blocks_modup(const Layout &lo, Slots sl) {
       }
     }
   }
-  for (uint32_t jl = 0; jl < lo.Mr; jl++) {                       // to NTT form, in place
+  for (uint32_t jl = jl0; jl < jl1; jl++) {                       // to NTT form, in place
     const uint32_t j = lo.owned_all[jl];
     Block b;
     setq(b, lo.mods_all[j]);
@@ -291,10 +293,11 @@ std::vector<Block> blocks_modup(const Layout &lo, Slots sl) {
 
 // regions (hoisted rotations in one pass): slot b is rotation b of the ONE decomposed ciphertext in slot 0, with its key
 // in key region regions[b]
-std::vector<Block> blocks_inner(const Layout &lo, bool hoisted, const std::vector<uint32_t> *regions) {
+std::vector<Block> blocks_inner(const Layout &lo, bool hoisted, const std::vector<uint32_t> *regions, uint32_t jl0 = 0, uint32_t jl1 = ~0u) {
   std::vector<Block> bl;
   const uint32_t nb = regions ? (uint32_t)regions->size() : lo.B;
-  for (uint32_t jl = 0; jl < lo.Mr; jl++) {
+  jl1 = std::min(jl1, lo.Mr);
+  for (uint32_t jl = jl0; jl < jl1; jl++) {
     const uint32_t j = lo.owned_all[jl];
     for (uint32_t bi = 0; bi < nb; bi++) {
       Block b;
@@ -468,6 +471,37 @@ bool pack(const std::vector<Block> &blocks, uint32_t n, std::vector<std::vector<
   return true;
 }
 
+// Phase 2 ("mid": ModUp sums, transforms, inner products) as programs.  The three loops of one modulus form a chain --
+// sums -> forward transforms -> inner products over the transformed limbs -- that the engine's sequencer runs as two
+// fused kernels when it sees the whole chain in ONE run (vp_engine.cpp, "staged batches").  A phase that does not fit
+// the 4096-word ROM is therefore cut BY MODULUS, every program holding all three loops of its moduli, not loop by loop.
+bool mid_programs(const Layout &lo, std::vector<std::vector<uint32_t>> *progs) {
+  const Slots all{lo.B};
+  auto size_of = [&](uint32_t a, uint32_t b) {
+    size_t n = 2;                                                 // vsetvl + break
+    for (const Block &x : blocks_modup(lo, all, a, b)) n += x.size();
+    for (const Block &x : blocks_inner(lo, false, nullptr, a, b)) n += x.size();
+    return n;
+  };
+  if (!lo.Mr) return true;
+  const size_t total = size_of(0, lo.Mr);
+  uint32_t nchunks = (uint32_t)((total + kDepth - 1) / kDepth);
+  for (; nchunks <= lo.Mr; nchunks++) {                           // equal shares of the moduli; one more program if a share does not fit
+    const uint32_t per = (lo.Mr + nchunks - 1) / nchunks;
+    bool fits = true;
+    for (uint32_t a = 0; a < lo.Mr && fits; a += per) fits = size_of(a, a + per) <= kDepth;
+    if (!fits) continue;
+    for (uint32_t a = 0; a < lo.Mr; a += per) {
+      std::vector<Block> bl = blocks_modup(lo, all, a, a + per), inner = blocks_inner(lo, false, nullptr, a, a + per);
+      bl.insert(bl.end(), inner.begin(), inner.end());
+      const size_t before = progs->size();
+      if (!pack(bl, lo.n, progs) || progs->size() != before + 1) return false;
+    }
+    return true;
+  }
+  return false;
+}
+
 // ---- RCCL, loaded on demand -------------------------------------------------------------------------------------
 struct RcclUid { char b[128]; };     // ncclUniqueId (rccl/nccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
 struct Rccl {
@@ -566,9 +600,21 @@ Layout layout_of(const aloha_ks_config *c) {
   return lo;
 }
 
-aloha_status run_phase(aloha_ks *ks, const char *name, uint64_t step, uint64_t ksk_row = 0) {
+// scratch_slot / scratch_slots: slots of the layout that only this phase's own instructions read back (the lifted digits
+// between their transform and the inner product, the mod-down's t): the engine's scratch window for the run
+// (aloha_vp_set_scratch), so that it need not write them to memory
+aloha_status run_phase(aloha_ks *ks, const char *name, uint64_t step, uint64_t ksk_row = 0, uint64_t scratch_slot = 0, uint64_t scratch_slots = 0) {
   auto it = ks->progs.find(name);
   if (it == ks->progs.end()) return ALOHA_OK;
+  struct Window {
+    aloha_vp *vp;
+    ~Window() { if (vp) (void)aloha_vp_set_scratch(vp, 0, 0); }
+  } window{nullptr};
+  if (scratch_slots && !it->second.empty()) {
+    aloha_status s = aloha_vp_set_scratch(ks->vp, ks->lo.row(scratch_slot), scratch_slots * ks->lo.rows);
+    if (s) return ks_fail(ks, s, "scratch window of phase %s: %s", name, aloha_vp_last_error(ks->vp));
+    window.vp = ks->vp;
+  }
   for (uint32_t idx = 0; idx < it->second.size(); idx++) {
     const std::vector<uint32_t> &w = it->second[idx];
     uint32_t pc = 0;
@@ -619,10 +665,10 @@ aloha_status key_switch(aloha_ks *ks, const char *first, const char *finish, uin
   const Layout &lo = ks->lo;
   aloha_status s = run_phase(ks, first, step);
   if (!s) s = all_gather(ks, lo.row(lo.y), (uint64_t)lo.Yr * lo.B * lo.n);
-  if (!s) s = run_phase(ks, "mid", 0);
+  if (!s) s = run_phase(ks, "mid", 0, 0, lo.sd, (uint64_t)lo.Mr * lo.dnum * lo.B);
   if (!s) s = run_phase(ks, "terms", 0);
   if (!s) s = all_gather(ks, lo.row(lo.w), (uint64_t)lo.Wr * lo.B * lo.n);
-  if (!s) s = run_phase(ks, finish, 0);
+  if (!s) s = run_phase(ks, finish, 0, 0, lo.s2, 2ull * lo.Lr * lo.B);
   return s;
 }
 
@@ -666,9 +712,9 @@ aloha_status aloha_ks_create(aloha_vp *vp, const aloha_ks_config *cfg, aloha_ks 
   add("rot1", lo.Lr, blocks_phase1(lo, ref1 ? ROTATE_REF : ROTATE, all));
   add("mul1", lo.Lr, blocks_phase1(lo, MULTIPLY, all));
   {
-    std::vector<Block> mid = blocks_modup(lo, all), inner = blocks_inner(lo, false, nullptr);
-    mid.insert(mid.end(), inner.begin(), inner.end());
-    add("mid", lo.Mr, mid);
+    std::vector<std::vector<uint32_t>> p;
+    if (lo.Mr && !mid_programs(lo, &p)) ok = false;
+    ks->progs["mid"] = std::move(p);
   }
   add("terms", !lo.owned_sp.empty(), blocks_terms(lo, all));
   add("fin_rot", lo.Lr, blocks_finish(lo, false, false, nullptr));
@@ -834,8 +880,9 @@ aloha_status aloha_ks_multiply(aloha_ks *ks) {
 aloha_status aloha_ks_stage(aloha_ks *ks, int op, int stage, uint64_t k) {
   if (!ks || !ks->vp || (op != 0 && op != 1) || stage < 0 || stage > 2) return ALOHA_ERR_ARG;
   if (stage == 0) return run_phase(ks, op ? "mul1" : "rot1", op ? 0 : k);
-  if (stage == 2) return run_phase(ks, op ? "fin_mul" : "fin_rot", 0);
-  aloha_status s = run_phase(ks, "mid", 0);
+  const Layout &lo = ks->lo;
+  if (stage == 2) return run_phase(ks, op ? "fin_mul" : "fin_rot", 0, 0, lo.s2, 2ull * lo.Lr * lo.B);
+  aloha_status s = run_phase(ks, "mid", 0, 0, lo.sd, (uint64_t)lo.Mr * lo.dnum * lo.B);
   if (!s) s = run_phase(ks, "terms", 0);
   return s;
 }
@@ -905,7 +952,7 @@ aloha_status aloha_ks_rotate_hoisted(aloha_ks *ks, uint64_t k, uint32_t index) {
   aloha_status s = run_phase(ks, "inner_h", 0, index * lo.ksk_limbs() * lo.rows);
   if (!s) s = run_phase(ks, "terms", 0);
   if (!s) s = all_gather(ks, lo.row(lo.w), (uint64_t)lo.Wr * lo.B * lo.n);
-  if (!s) s = run_phase(ks, "fin_h", k);
+  if (!s) s = run_phase(ks, "fin_h", k, 0, lo.s2, 2ull * lo.Lr * lo.B);
   return s;
 }
 
@@ -927,7 +974,7 @@ aloha_status aloha_ks_rotate_hoisted_many(aloha_ks *ks, const uint64_t *steps, c
   aloha_status s = run_phase(ks, "many", 0);
   if (!s) s = run_phase(ks, "many_terms", 0);
   if (!s) s = all_gather(ks, lo.row(lo.w), (uint64_t)lo.Wr * lo.B * lo.n);
-  if (!s) s = run_phase(ks, "many_fin", 0);
+  if (!s) s = run_phase(ks, "many_fin", 0, 0, lo.s2, 2ull * lo.Lr * lo.B);
   return s;
 }
 
@@ -938,7 +985,7 @@ aloha_status aloha_ks_rescale(aloha_ks *ks) {
   const Layout &lo = ks->lo;
   aloha_status s = run_phase(ks, "rescale1", 0);
   if (!s) s = all_gather(ks, lo.row(lo.w), (uint64_t)lo.Wr * lo.B * lo.n);
-  if (!s) s = run_phase(ks, "rescale2", 0);
+  if (!s) s = run_phase(ks, "rescale2", 0, 0, lo.s2, 2ull * lo.Lr * lo.B);
   return s;
 }
 

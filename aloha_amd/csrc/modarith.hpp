@@ -254,4 +254,21 @@ ALOHA_DEV u64 mulmod_barrett(u64 a, u64 b, u64 q, u64 mu) {
   return csub(zl - qhat * q, q);
 }
 
+// The same product on the pinned multiplier forms, without the final conditional subtraction: a, b < 2^60, result in
+// [0, 2q).  The 128-bit product is four multiply-adds (each partial product rides the carry of the one before), the
+// quotient the exact high word of x1 * mu (wave-uniform mu: SGPR operands), the remainder one multiply-add chain on the
+// low word.  ~19 instructions; used where a product's second factor is a vector (the key of the inner product).
+ALOHA_DEV u64 mulmod_lazy_2q(u64 a, u64 b, u64 nq, u64 mu) {
+  const u32 a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+  const u64 p00 = mad32_z(a0, b0);
+  const u64 m1 = mad32(a0, b1, (u64)hi32(p00));                 // < 2^64: (2^32-1)^2 + 2^32 - 1
+  const u64 m2 = mad32(a1, b0, (u64)lo32(m1));
+  const u64 m3 = mad32(a1, b1, (u64)hi32(m1));
+  const u64 zh = m3 + hi32(m2), zl = pack64(lo32(p00), lo32(m2));
+  const u64 x1 = (zh << 7) | (zl >> 57);
+  const u64 qhat = shoup_qhat_exact<true>(x1, mu);              // floor(x1 * mu / 2^64)
+  const u64 acc = mad32_s(lo32(qhat), lo32(nq), zl);            // zl + qhat * nq  (mod 2^64)  ==  zl - qhat * q
+  return pack64(lo32(acc), hi32(acc) + mullo32_s(hi32(qhat), lo32(nq)) + mullo32_s(lo32(qhat), hi32(nq)));
+}
+
 }  // namespace aloha

@@ -57,15 +57,9 @@ constexpr int bound_after4(int b) { return next_bound(next_bound(next_bound(next
 
 // radix-16 step on 16 registers: sub-stage ss pairs v[i] with v[i + (8 >> ss)]; group g of
 // sub-stage ss takes twiddle tw(ss, g).  BIN = input bound; output bound = bound_after4(BIN).
-// ALOHA_ABLATE (timing experiments only, results invalid): 1 = no butterflies (memory + LDS
-// skeleton), 2 = no global loads/stores (arithmetic + LDS skeleton).
-#ifndef ALOHA_ABLATE
-#define ALOHA_ABLATE 0
-#endif
-
 template <bool UNI, int BIN, typename TW>
 __device__ __forceinline__ void fwd_radix16(u64 (&v)[16], const TW &tw, u64 q, u64 nq) {
-#if ALOHA_ABLATE == 1
+#if defined(ALOHA_EXPERIMENTS) && defined(ALOHA_ABLATE) && ALOHA_ABLATE == 1   // variant builds only: memory + LDS skeleton (results invalid)
   return;
 #endif
   constexpr int B[5] = {BIN, next_bound(BIN), next_bound(next_bound(BIN)),
@@ -252,6 +246,16 @@ struct TwStepB {                   // stages s' = 4..7: L = 2^(4+ss) + kh*2^ss +
   int kh;
   __device__ __forceinline__ tw_t operator()(int ss, int g) const {
     return load_tw(blk + (16 << ss) + (kh << ss) + g);
+  }
+};
+
+template <int NPRE>
+struct TwStepMixA {                // first step of a line with a block of its own: the first NPRE entries preloaded, the rest read at use
+  const tw_t (&r)[15];
+  ctw_t blk;
+  __device__ __forceinline__ tw_t operator()(int ss, int g) const {
+    const int idx = (1 << ss) - 1 + g;
+    return idx < NPRE ? r[idx] : load_tw(blk + (1 << ss) + g);
   }
 };
 

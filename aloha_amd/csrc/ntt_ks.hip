@@ -1,0 +1,345 @@
+// ntt_ks.hip -- the forward transforms of a key-switch at N = 2^16 fused with what surrounds them (gfx950).
+//
+// The reference's key-switch (sim/vp/isram_file_generator/keyswitch.mem:1-122) is a chain of whole-limb instructions:
+// basis extension of a digit (:9-14,:29-34), vntt of the extended limb, product with the key and accumulation over the
+// digits (:46-79), and in the mod-down a basis change (:86-91), vntt (:94-99) and (acc - t) * P^-1 + base (:102-117).
+// Run instruction by instruction every intermediate limb makes a round trip through HBM.  The sequencer
+// (vp_engine.cpp) recognises these chains in a program and hands them to the kernels below, which are the two-pass
+// transform of ntt_tile.hip with the neighbouring element-wise work folded into its passes:
+//   ntt_col_pro_kernel   column pass whose input is  sum_t a_t * s_t + cst  formed in its loads        (SumSrc)
+//   ntt_row_epi_kernel   row pass that ends in  t * s0 + sum_i a_i * s_i + cst  instead of storing t    (RowEpi)
+//   ntt_rowdot_kernel    row pass of all digits of one modulus, times the key rows, summed over the digits:
+//                        two limbs leave where dnum transformed limbs would have been written and read back (RowDotGroup)
+// All results are the canonical residues the instruction-by-instruction execution produces (the transforms are exact
+// and every sum is reduced to [0, q) at the end): bit-exact against the oracle's ISA machine in tests/.
+#include <cstdlib>
+
+#include "kernels.hpp"
+#include "modarith.hpp"
+#include "ntt_device.hpp"
+#include "ntt_tiles.hpp"
+
+namespace aloha {
+namespace k {
+
+namespace {
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_col_pro_kernel(const LimbJob *__restrict__ jobs, const PrimeDev *__restrict__ primes, uint32_t count,
+                                                          const SumSrc *__restrict__ sums) {
+  __shared__ u64 sdata[LINES * PITCH];
+  // XCD-affine tile order, as in ntt_col_kernel
+  const uint32_t b = blockIdx.x, full = (count >> 3) << 7;
+  const uint32_t limb = b < full ? ((b >> 7) << 3) + (b & 7) : (b >> 4);
+  const uint32_t cg = b < full ? (b >> 3) & 15 : (b & 15);
+  const LimbJob jb = jobs[limb];
+  col_tile_fwd<true, false, true>(sdata, jb, &primes[jb.prime], cg, threadIdx.x, sums);
+}
+
+// Row pass (second pass of a forward transform) whose lines may end in an epilogue.  A line with an epilogue is not
+// canonicalised first: its Shoup product takes any 64-bit value.
+template <bool UNIA>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void ntt_row_epi_kernel(const LimbJob *__restrict__ jobs,
+                                                                                                 const PrimeDev *__restrict__ primes,
+                                                                                                 const TileDesc *__restrict__ tiles,
+                                                                                                 const RowEpi *__restrict__ epis) {
+  __shared__ u64 lds[4 * RP];
+  const TileDesc td = tiles[blockIdx.x >> 2];
+  const uint32_t w = blockIdx.x & 3;
+  const int lane = threadIdx.x;
+  const uint32_t first_limb = td.first_limb, pb_log = td.pb_log, chunk = td.chunk;
+  const uint32_t pb_mask = (1u << pb_log) - 1, rpt = 16u >> pb_log;
+  const LimbJob j0 = jobs[first_limb];
+  const PrimeDev *pr = &primes[j0.prime];
+  const u64 q = pr->m.q, nq = pr->m.nq;
+  const u32 kc = (u32)pr->m.kc;
+  ctw_t gtw = (ctw_t)pr->tw.fwd_blk + TW_BLK;
+  const RowLanes L(lane);
+  const uint32_t lineA = 4 * w + L.lwA, lineB = 4 * w + L.lwB;
+  const uint32_t rowA = chunk * rpt + (lineA >> pb_log), rowB = chunk * rpt + (lineB >> pb_log);
+  const uint32_t rowU = chunk * rpt + ((4 * w) >> pb_log);
+  ctw_t blkA = gtw + (size_t)(UNIA ? rowU : rowA) * TW_BLK;
+  ctw_t blkB = gtw + (size_t)(UNIA ? rowU : rowB) * TW_BLK;
+  const LimbJob jA = jobs[first_limb + (lineA & pb_mask)];
+  const uint32_t off = (rowA << 8) + L.plA;
+  cgptr_t src = (cgptr_t)jA.src + off;
+  gptr_t dst = (gptr_t)jA.dst + off;
+  // the epilogue's scalars and operand pointers travel with the line: loaded now, behind the data loads
+  const RowEpi *e = epis + (jA.epi ? jA.epi - 1 : 0);
+  const bool has = jA.epi != 0;                                  // (per line: the 16 lanes of a line agree)
+  u64 es[kEpiOps + 1], esp[kEpiOps + 1], cst = 0;
+  cgptr_t ea[kEpiOps];
+  gptr_t out = dst;
+  uint32_t nops = 0, store_t = 1;
+  u64 v[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++) v[kk] = ld_stream(&src[16 * kk]);
+  if (has) {
+#pragma unroll
+    for (int i = 0; i <= kEpiOps; i++) { es[i] = e->s[i]; esp[i] = e->sp[i]; }
+#pragma unroll
+    for (int i = 0; i < kEpiOps; i++) ea[i] = (cgptr_t)e->a[i] + off;
+    cst = e->cst; out = (gptr_t)e->out + off; nops = e->nops; store_t = e->store_t;
+  }
+  row_fwd_core<UNIA, FWD_MID, false>(v, lds, L, blkA, blkB, pr);
+  if (has) {
+    // the first two operands' loads go out together, ahead of the product with the transform
+    u64 x0[16], x1[16];
+    if (nops > 0) {
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) x0[kk] = ea[0][16 * kk];
+    }
+    if (nops > 1) {
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) x1[kk] = ea[1][16 * kk];
+    }
+    if (store_t) {
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) st_stream(&dst[16 * kk], canon_any(v[kk], q, nq, kc));
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) v[kk] = mul_shoup_4q<false>(v[kk], es[0], esp[0], nq);       // < 4q
+    if (nops > 0) {
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) v[kk] += mul_shoup_4q<false>(x0[kk], es[1], esp[1], nq);
+    }
+    if (nops > 1) {
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) v[kk] += mul_shoup_4q<false>(x1[kk], es[2], esp[2], nq);
+    }
+    if (nops > 2) {                                              // <= 4 products < 4q: < 16q
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) v[kk] += mul_shoup_4q<false>(ea[2][16 * kk], es[3], esp[3], nq);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) st_stream(&out[16 * kk], csub_u(canon_any(v[kk], q, nq, kc) + cst, q));
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) st_stream(&dst[16 * kk], canon_any(v[kk], q, nq, kc));
+  }
+}
+
+// ---- row pass + inner product with the key -----------------------------------------------------------------------
+// One wave per (group, R consecutive rows); group = one modulus of one ciphertext (RowDotGroup).  The wave walks the
+// group's digits and keeps the two accumulators of its R rows in registers:
+//   * four digits at a time as a row tile of the shape the plain row pass uses for bundles of 4 limbs -- 4 lines = the
+//     SAME row of 4 digits, one twiddle block through scalar loads -- once per row;
+//   * the remaining 1-3 transformed digits, and the digits that arrive in NTT form already (the limb to switch under
+//     its own digit's moduli), as tiles of 4 / R digits x R rows.
+// After a tile a lane (pl, lw) holds line lw's 16 points pl + 16k.  They are multiplied by the key's words at the same
+// positions (mulmod_lazy_2q, < 2q) and then leave the lane: v_permlane32_swap / v_permlane16_swap (gfx950) exchange
+// register pairs between the lane groups 32 and 16 apart, so that two swaps turn "16 points of one line" into
+// "4 points of four lines" -- ADDED where the lines exchanged are digits of one row (a reduce-scatter), kept apart where
+// they are rows of one digit (a transpose).  Either way lane (pl, lw) ends with the 4 points
+//   k = 4m + 2(lw & 1) + (lw >> 1),  m = 0..3
+// of each of the wave's rows: R x 4 x 2 accumulators, lazily < 8q; the stores at the end are 128-byte segments again.
+// R = 4: 168 VGPRs, 3 waves per SIMD, no idle lines.  R = 2: half the accumulators and no twiddle preload -> 4 waves per
+// SIMD and twice the waves (a key-switch has few groups: 28 at L = 24), an odd leftover digit leaves two lines idle.
+__device__ __forceinline__ void swap32(u64 &x, u64 &y) {        // lanes >= 32 of x  <->  lanes < 32 of y
+  const auto lo = __builtin_amdgcn_permlane32_swap(lo32(x), lo32(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(hi32(x), hi32(y), false, false);
+  x = pack64(lo[0], hi[0]);
+  y = pack64(lo[1], hi[1]);
+}
+__device__ __forceinline__ void swap16(u64 &x, u64 &y) {        // odd 16-lane rows of x  <->  even rows of y
+  const auto lo = __builtin_amdgcn_permlane16_swap(lo32(x), lo32(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(hi32(x), hi32(y), false, false);
+  x = pack64(lo[0], hi[0]);
+  y = pack64(lo[1], hi[1]);
+}
+
+// Line lw of a tile = (digit index lw >> DSH, row index lw & ((1 << DSH) - 1)):  DSH = 0: four digits of one row;
+// DSH = 1: two digits x two rows;  DSH = 2: one digit x four rows.  The exchange over lane bit 1 of lw (32 apart) adds
+// when that bit selects a digit (DSH <= 1), the exchange over bit 0 (16 apart) adds when it does (DSH == 0).
+// products of the lane's points 4m .. 4m+3 with the two key rows (`live`: lines without a digit contribute nothing), then
+// the exchange: r[i][c] = row i's contribution at the lane's point of chunk m.
+template <int DSH>
+__device__ __forceinline__ void products_chunk(const u64 (&v)[16], int m, cgptr_t key0, cgptr_t key1, bool live, u64 nq, u64 mu,
+                                               u64 (&r)[1 << DSH][2]) {
+  u64 p[4][2];
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      p[j][0] = key0[16 * (4 * m + j)];
+      p[j][1] = key1[16 * (4 * m + j)];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int c = 0; c < 2; c++) p[j][c] = mulmod_lazy_2q(v[4 * m + j], p[j][c], nq, mu);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) p[j][0] = p[j][1] = 0;
+  }
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    // lanes 32 apart, pairs (4m, 4m+1) and (4m+2, 4m+3): a lane keeps k = k0 + (lw >> 1); x <-> lw bit 1 clear, y <-> set
+    swap32(p[0][c], p[1][c]);
+    swap32(p[2][c], p[3][c]);
+    if (DSH <= 1) {
+      u64 s0 = p[0][c] + p[1][c], s1 = p[2][c] + p[3][c];       // < 4q
+      swap16(s0, s1);                                           // lanes 16 apart: a lane keeps j = 2m + (lw & 1); x <-> lw bit 0 clear
+      if (DSH == 0) r[0][c] = s0 + s1;                          // < 8q
+      else { r[0][c] = s0; r[1][c] = s1; }
+    } else {
+      swap16(p[0][c], p[2][c]);                                 // rows 0 | 1
+      swap16(p[1][c], p[3][c]);                                 // rows 2 | 3
+      r[0][c] = p[0][c]; r[1][c] = p[2][c]; r[2][c] = p[1][c]; r[3][c] = p[3][c];
+    }
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 2 ? 4 : 3, R == 2 ? 4 : 3))) void ntt_rowdot_kernel(
+    const RowDotGroup *__restrict__ groups, const PrimeDev *__restrict__ primes) {
+  constexpr int DSH = R == 4 ? 2 : 1, DPT = 4 / R;               // remainder tiles: DPT digits x R rows
+  constexpr int PRE = R == 2 ? 0 : 3;                            // second-step twiddles issued early (registers against latency)
+  constexpr uint32_t WPG = 256 / R;                              // waves per group
+  __shared__ u64 lds[4 * RP];
+  const RowDotGroup *g = &groups[blockIdx.x / WPG];
+  const uint32_t r0 = (blockIdx.x % WPG) * R;
+  const int lane = threadIdx.x;
+  const PrimeDev *pr = &primes[g->prime];
+  const u64 q = pr->m.q, nq = pr->m.nq, mu = pr->m.mu;
+  const u32 kc = (u32)pr->m.kc;
+  ctw_t gtw = (ctw_t)pr->tw.fwd_blk + TW_BLK;
+  const RowLanes L(lane);
+  const uint32_t nt = g->nt, np = g->np;
+  const u64 eightq = q << 3;
+  u64 A[R][4][2];
+#pragma unroll
+  for (int i = 0; i < R; i++)
+#pragma unroll
+    for (int m = 0; m < 4; m++) A[i][m][0] = A[i][m][1] = 0;
+
+  // The digits are walked in BLOCKS -- four transformed digits over the wave's R rows (R tiles), or one tile of DPT
+  // left-over transformed / plain digits -- and every wave starts at a different block of the cycle: waves that share a
+  // SIMD would otherwise all wait for their loads, then all compute, in step (the sum does not care about the order).
+  const uint32_t nquad = nt >> 2, ntr = (nt - 4 * nquad + DPT - 1) / DPT, npl = (np + DPT - 1) / DPT;
+  const uint32_t nblocks = nquad + ntr + npl;
+  const uint32_t rowA = r0 + (L.lwA & (R - 1)), rowB = r0 + (L.lwB & (R - 1));
+  const uint32_t offP = (rowA << 8) + L.plA;
+  ctw_t blkA = gtw + (size_t)rowA * TW_BLK, blkB = gtw + (size_t)rowB * TW_BLK;
+  uint32_t b = (blockIdx.x >> 3) % nblocks;                      // (blocks 8 apart share an XCD)
+  for (uint32_t bi = 0; bi < nblocks; bi++, b = b + 1 == nblocks ? 0 : b + 1) {
+    if (b < nquad) {
+      // -- four digits, row by row: 4 lines = row r0 + i of digits 4 b + lw ------------------------------------------------
+      const uint32_t dA = 4 * b + L.lwA;
+      cgptr_t xs = (cgptr_t)g->x[dA], k0 = (cgptr_t)g->key[dA][0], k1 = (cgptr_t)g->key[dA][1];
+      gptr_t xo = (gptr_t)g->xout[dA];
+      for (uint32_t i = 0; i < R; i++) {
+        const uint32_t row = r0 + i;                             // (wave-uniform)
+        const uint32_t off = (row << 8) + L.plA;
+        cgptr_t src = xs + off;
+        ctw_t blk = gtw + (size_t)row * TW_BLK;
+        u64 v[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) v[kk] = ld_stream(&src[16 * kk]);
+        row_fwd_core<true, FWD_MID, true, PRE>(v, lds, L, blk, blk, pr);
+        if (xo) {
+#pragma unroll
+          for (int kk = 0; kk < 16; kk++) st_stream(&(xo + off)[16 * kk], v[kk]);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          u64 r[1][2];
+          products_chunk<0>(v, m, k0 + off, k1 + off, true, nq, mu, r);
+          A[0][m][0] = csub_u(A[0][m][0] + r[0][0], eightq);    // both < 8q
+          A[0][m][1] = csub_u(A[0][m][1] + r[0][1], eightq);
+        }
+        // the next row accumulates into A[0] again: rotate the rows (register moves; identity after R)
+        u64 t[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; m++) { t[m][0] = A[0][m][0]; t[m][1] = A[0][m][1]; }
+#pragma unroll
+        for (int ii = 0; ii + 1 < R; ii++)
+#pragma unroll
+          for (int m = 0; m < 4; m++) { A[ii][m][0] = A[ii + 1][m][0]; A[ii][m][1] = A[ii + 1][m][1]; }
+#pragma unroll
+        for (int m = 0; m < 4; m++) { A[R - 1][m][0] = t[m][0]; A[R - 1][m][1] = t[m][1]; }
+      }
+    } else {
+      // -- DPT digits over the wave's R rows: transformed ones left over by the groups of four, or plain ones --------------
+      const bool transformed = b < nquad + ntr;
+      const uint32_t d0 = transformed ? 4 * nquad + (b - nquad) * DPT : nt + (b - nquad - ntr) * DPT;
+      const uint32_t end = transformed ? nt : nt + np;          // a tile holds digits of one kind
+      const uint32_t d = d0 + (L.lwA >> (R == 4 ? 2 : 1));      // the lane's digit (A mapping)
+      const bool live = R == 4 ? true : d < end;                // (R = 4: one digit per tile, every line has it)
+      const uint32_t dd = live ? d : d0;                         // (idle lines read the first digit's rows: defined data, zero weight)
+      cgptr_t src = (cgptr_t)g->x[dd] + offP;
+      u64 v[16];
+      if (transformed) {
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) v[kk] = ld_stream(&src[16 * kk]);
+        row_fwd_core<false, FWD_MID, true, PRE, (R == 2 ? 7 : 3)>(v, lds, L, blkA, blkB, pr);
+        gptr_t xo = (gptr_t)g->xout[dd];
+        if (live && xo) {
+#pragma unroll
+          for (int kk = 0; kk < 16; kk++) st_stream(&(xo + offP)[16 * kk], v[kk]);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) v[kk] = src[16 * kk];   // NTT form already; any word < 2^60 (modalu.sv:44-46)
+      }
+      cgptr_t key0 = (cgptr_t)g->key[dd][0] + offP, key1 = (cgptr_t)g->key[dd][1] + offP;
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        u64 r[R][2];
+        products_chunk<DSH>(v, m, key0, key1, live, nq, mu, r);
+#pragma unroll
+        for (int i = 0; i < R; i++)
+#pragma unroll
+          for (int c = 0; c < 2; c++) A[i][m][c] = csub_u(A[i][m][c] + r[i][c], eightq);   // < 8q + 4q
+      }
+    }
+  }
+
+  // -- canonical results, 128-byte segments ----------------------------------------------------------------------------
+  const uint32_t kbase = 2 * (L.lwA & 1) + (L.lwA >> 1);
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    gptr_t out = (gptr_t)g->out[c] + L.plA;
+#pragma unroll
+    for (int i = 0; i < R; i++)
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+        st_stream(&out[((r0 + i) << 8) + 16 * (4 * m + kbase)], canon_any(A[i][m][c], q, nq, kc));
+  }
+}
+
+}  // namespace
+
+hipError_t ntt_fwd16_cols(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count, const SumSrc *d_sums,
+                          uint64_t *launches) {
+  if (!count) return hipSuccess;
+  hipLaunchKernelGGL(ntt_col_pro_kernel, dim3(count * 16), dim3(256), 0, st, d_jobs, d_primes, count, d_sums);
+  if (launches) ++*launches;
+  return hipGetLastError();
+}
+
+hipError_t ntt_fwd16_rows(hipStream_t st, const LimbJob *d_inplace, const PrimeDev *d_primes, const TileDesc *d_uni_tiles, uint32_t n_uni,
+                          const TileDesc *d_glb_tiles, uint32_t n_glb, const RowEpi *d_epis, uint64_t *launches) {
+  if (n_uni) {
+    hipLaunchKernelGGL((ntt_row_epi_kernel<true>), dim3(n_uni * 4), dim3(64), 0, st, d_inplace, d_primes, d_uni_tiles, d_epis);
+    if (launches) ++*launches;
+  }
+  if (n_glb) {
+    hipLaunchKernelGGL((ntt_row_epi_kernel<false>), dim3(n_glb * 4), dim3(64), 0, st, d_inplace, d_primes, d_glb_tiles, d_epis);
+    if (launches) ++*launches;
+  }
+  return hipGetLastError();
+}
+
+hipError_t ntt_fwd16_rowdot(hipStream_t st, const RowDotGroup *d_groups, uint32_t ngroups, const PrimeDev *d_primes, uint64_t *launches) {
+  if (!ngroups) return hipSuccess;
+  // few groups (a key-switch of one ciphertext: 28 at L = 24): two rows per wave, twice the waves at 4 per SIMD; batches
+  // of ciphertexts fill the chip with four rows per wave and no idle lines.  (ALOHA_ROWDOT_ROWS: A/B timing switch)
+  static const int forced = getenv("ALOHA_ROWDOT_ROWS") ? atoi(getenv("ALOHA_ROWDOT_ROWS")) : 0;
+  const bool two = forced ? forced == 2 : ngroups < 96;
+  if (two) hipLaunchKernelGGL(ntt_rowdot_kernel<2>, dim3(ngroups * 128), dim3(64), 0, st, d_groups, d_primes);
+  else hipLaunchKernelGGL(ntt_rowdot_kernel<4>, dim3(ngroups * 64), dim3(64), 0, st, d_groups, d_primes);
+  if (launches) ++*launches;
+  return hipGetLastError();
+}
+
+}  // namespace k
+}  // namespace aloha

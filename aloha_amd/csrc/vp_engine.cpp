@@ -64,15 +64,18 @@ struct TransformPlan {           // device-side description of one batched trans
   std::vector<PlanChunk> chunks; // empty => radix-2 stage launches only
   LimbJob *d_jobs = nullptr;
   TileDesc *d_tiles = nullptr;
-  // fused forward transform (N = 2^16, every row tile a bundle tile): ticket list + control words (kernels.hpp)
+#ifdef ALOHA_EXPERIMENTS   // single-launch forward transform (experiments/ntt_tile_knobs.hip): ticket list + control words
   uint64_t *d_tickets = nullptr;
   uint32_t *d_ctl = nullptr;
   uint32_t npos = 0;
+#endif
   ~TransformPlan() {
     if (d_jobs) (void)hipFree(d_jobs);
     if (d_tiles) (void)hipFree(d_tiles);
+#ifdef ALOHA_EXPERIMENTS
     if (d_tickets) (void)hipFree(d_tickets);
     if (d_ctl) (void)hipFree(d_ctl);
+#endif
   }
 };
 
@@ -106,11 +109,14 @@ struct aloha_vp {
   std::vector<std::pair<std::vector<uint8_t>, void *>> blobs;   // cached device copies of batched job arrays
   uint32_t max_slots = kMaxPrimes;   // twiddle sets kept at once (ALOHA_MAX_TWIDDLE_SETS lowers it: tests of the generation reset)
   uint32_t chunk_limbs = 0;      // limbs per chunk of a batched transform (0 = whole batch; chunking did not pay)
-  // fused single-launch forward transform at N = 2^16 (ntt_tile.hip): batches of at least fused_min limbs
-  uint32_t fused_min = 0, fused_delay = 8, fused_wgs = 0;   // off by default: measured slower than two launches
+#ifdef ALOHA_EXPERIMENTS   // variant builds only (python -m aloha_amd.build --variant): measured and rejected, DESIGN.md 3.2 / 5
+  // single-launch forward transform at N = 2^16 (experiments/ntt_tile_knobs.hip): batches of at least fused_min limbs
+  uint32_t fused_min = 0, fused_delay = 8, fused_wgs = 0;
   uint32_t *d_fused_status = nullptr;                // sticky: non-zero after a fused launch gave up on a bounded wait
   bool fused_stats = false;                          // ALOHA_NTT_FUSED_STATS: print the scheduler's wait counts after every fused launch
   bool fused_unchecked = false;                      // a fused launch ran since the status word was last read
+  bool graphs_on = false;                            // ALOHA_RUN_GRAPH=1: replay recorded runs as hipGraphs (measured SLOWER on ROCm 7.2)
+#endif
   // CKKS encoder: tables per ring size, staging buffers
   struct EncTab { aloha::k::EncodeTables t{}; void *alloc = nullptr; };
   std::map<unsigned, EncTab> enc_tables;
@@ -126,11 +132,11 @@ struct aloha_vp {
     uint32_t pc = 0;
     uint64_t epoch = 0, instructions = 0;
     std::vector<std::function<hipError_t()>> ops;
-    // ALOHA_RUN_GRAPH=1 (experiment, off): from its second replay on a list becomes a hipGraph -- the launches captured once
+    uint64_t scratch_row = 0, scratch_rows = 0;      // the scratch window the run was sequenced under (aloha_vp_set_scratch)
+    // Variant builds, ALOHA_RUN_GRAPH=1: from its second replay on a list becomes a hipGraph -- the launches captured once
     // from `ops` on the handle's stream, re-issued by ONE hipGraphLaunch.  Measured on ROCm 7.2 / MI355X it is SLOWER for
     // these 4-7 kernel graphs: ~50 us of host time per hipGraphLaunch against ~3 us per plain launch (rank 0's share of a
-    // sharded key-switch 0.43 ms instead of 0.11 ms, profiles/r02_l_ks_probe_*.jsonl), so the launch list stays the default.
-    // A list that cannot be captured stays a list.
+    // sharded key-switch 0.43 ms instead of 0.11 ms, profiles/r02_l_ks_probe_*.jsonl), so the launch list is what ships.
     hipGraphExec_t graph = nullptr;
     bool graph_failed = false;
     uint32_t replays = 0;
@@ -145,6 +151,7 @@ struct aloha_vp {
         inst = std::move(o.inst); imm = std::move(o.imm); ops = std::move(o.ops);
         memcpy(csr, o.csr, sizeof csr);
         step = o.step; vl_in = o.vl_in; q_in = o.q_in; mu_in = o.mu_in; vl_out = o.vl_out; q_out = o.q_out; mu_out = o.mu_out;
+        scratch_row = o.scratch_row; scratch_rows = o.scratch_rows;
         pc = o.pc; epoch = o.epoch; instructions = o.instructions;
         graph = o.graph; graph_failed = o.graph_failed; replays = o.replays; launches = o.launches;
         o.graph = nullptr;
@@ -157,7 +164,6 @@ struct aloha_vp {
   RunPlan *rec = nullptr;                            // non-null while a run is being recorded
   uint64_t epoch = 0;                                // bumped whenever a cached device object a plan may point to is freed
   bool run_cache_on = true;
-  bool graphs_on = false;                            // ALOHA_RUN_GRAPH=1: replay recorded runs as hipGraphs (measured SLOWER on ROCm 7.2, off)
   uint64_t scratch_row = 0, scratch_rows = 0;        // aloha_vp_set_scratch: SPM rows whose contents are undefined after a run that writes them
   aloha_vp_stats stats{};
   std::string err;
@@ -315,6 +321,10 @@ aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
 // After a synchronisation: did a fused transform give up on one of its bounded waits?  (It cannot in a correct
 // schedule -- see ntt_fused_fwd_kernel -- but a wait that can be bounded is, and the bound is reported.)
 aloha_status check_fused(aloha_vp *vp) {
+#ifndef ALOHA_EXPERIMENTS
+  (void)vp;
+  return ALOHA_OK;
+#else
   if (!vp->fused_unchecked) return ALOHA_OK;
   uint32_t st = 0;
   HIPCK(vp, hipMemcpyAsync(&st, vp->d_fused_status, 4, hipMemcpyDeviceToHost, vp->stream));
@@ -323,6 +333,7 @@ aloha_status check_fused(aloha_vp *vp) {
   if (!st) return ALOHA_OK;
   HIPCK(vp, hipMemsetAsync(vp->d_fused_status, 0, 4, vp->stream));
   return fail(vp, ALOHA_ERR_DEVICE, "fused N=2^16 transform gave up on a bounded wait (%u waits): its output is incomplete", st);
+#endif
 }
 
 // Batched transform of `count` limbs described by (src, dst, slot); the workhorse behind both
@@ -368,24 +379,28 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
       np->chunks.push_back(pc);
     }
     if (!tiled) np->chunks.clear();
+#ifdef ALOHA_EXPERIMENTS
     // N = 2^16, one chunk, every row tile a bundle tile, a batch large enough to fill the persistent grid: the forward
-    // transform runs as ONE launch with the intermediate handed over through the Infinity Cache (ntt_tile.hip)
+    // transform runs as ONE launch with the intermediate handed over through the Infinity Cache (experiments/ntt_tile_knobs.hip)
     std::vector<uint64_t> tickets;
     if (logn == 16 && np->chunks.size() == 1 && np->chunks[0].n_glb == 0 && vp->fused_min && count >= vp->fused_min &&
         !(vp->flags & ALOHA_FLAG_NTT_TWO_PASS))
       aloha::k::build_fused_schedule(tiles, logn - 8, vp->fused_delay, tickets);
+#endif
     HIPCK(vp, hipMalloc(&np->d_jobs, np->jobs.size() * sizeof(LimbJob)));
     HIPCK(vp, hipMemcpyAsync(np->d_jobs, np->jobs.data(), np->jobs.size() * sizeof(LimbJob), hipMemcpyHostToDevice, vp->stream));
     if (!tiles.empty()) {
       HIPCK(vp, hipMalloc(&np->d_tiles, tiles.size() * sizeof(TileDesc)));
       HIPCK(vp, hipMemcpyAsync(np->d_tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice, vp->stream));
     }
+#ifdef ALOHA_EXPERIMENTS
     if (!tickets.empty()) {
       np->npos = (uint32_t)tickets.size();
       HIPCK(vp, hipMalloc(&np->d_tickets, tickets.size() * 8));
       HIPCK(vp, hipMemcpyAsync(np->d_tickets, tickets.data(), tickets.size() * 8, hipMemcpyHostToDevice, vp->stream));
       HIPCK(vp, hipMalloc(&np->d_ctl, aloha::k::fused_ctl_words(count) * 4));
     }
+#endif
     HIPCK(vp, hipStreamSynchronize(vp->stream));    // pageable sources go out of scope
     if (vp->plans.size() >= kMaxPlans) {            // evict the oldest; its kernels have drained (sync above)
       vp->plans.erase(vp->plans.begin());
@@ -402,6 +417,7 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
     hipError_t e = hipSuccess;
     if (pl->chunks.empty()) {
       e = aloha::k::ntt_radix2_batch(vp->stream, pl->d_jobs, vp->d_primes, count, logn, 0, logn, inverse, true, true, &launches);
+#ifdef ALOHA_EXPERIMENTS
     } else if (!inverse && pl->d_tickets) {
       e = aloha::k::ntt_fused_fwd(vp->stream, pl->d_jobs, pl->d_jobs + count, vp->d_primes, pl->d_tiles + pl->chunks[0].uni_off,
                                   pl->d_tickets, pl->npos, count, pl->d_ctl, vp->d_fused_status, vp->fused_wgs, &launches);
@@ -413,6 +429,7 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
             hipStreamSynchronize(vp->stream) == hipSuccess)
           fprintf(stderr, "aloha fused ntt: %u limbs, %u positions, %u tiles waited, %u poll iterations\n", count, pl->npos, w[0], w[1]);
       }
+#endif
     } else {
       for (const PlanChunk &pc : pl->chunks) {
         e = aloha::k::ntt_tile_batch(vp->stream, pl->d_jobs, pl->d_jobs + count, vp->d_primes, pc.limb_begin,
@@ -506,8 +523,9 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   vp->max_logn = cfg->max_log_n;
   if (const char *e = getenv("ALOHA_NTT_CHUNK")) vp->chunk_limbs = (uint32_t)strtoul(e, nullptr, 10);
   vp->run_cache_on = !getenv("ALOHA_NO_RUN_CACHE");          // (A/B switch: every run goes through the sequencer again)
-  vp->graphs_on = getenv("ALOHA_RUN_GRAPH") != nullptr;
   if (const char *e = getenv("ALOHA_MAX_TWIDDLE_SETS")) vp->max_slots = std::min(kMaxPrimes, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));
+#ifdef ALOHA_EXPERIMENTS
+  vp->graphs_on = getenv("ALOHA_RUN_GRAPH") != nullptr;
   // fused single-launch forward transform (N = 2^16), an experiment kept behind a switch: ALOHA_NTT_FUSED = the smallest
   // batch it serves (unset or 0: never);
   // ALOHA_NTT_FUSED_DELAY = limb groups between a column tile and the row tiles that read it;
@@ -523,6 +541,7 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
     const char *m = getenv("ALOHA_NTT_FUSED_MODE");
     if (!(m && !strcmp(m, "persistent"))) vp->fused_wgs = 0;
   }
+#endif
   vp->inst.assign(ALOHA_IRAM_DEPTH, 0);
   vp->imm.assign(ALOHA_IRAM_DEPTH, 0);
   auto bail = [&](const char *what) {
@@ -545,8 +564,10 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   if (hipMalloc(&vp->d_vreg, vreg_bytes) != hipSuccess) return bail("hipMalloc(vreg)");
   if (hipMalloc(&vp->d_scratch, (size_t)8 << vp->max_logn) != hipSuccess) return bail("hipMalloc(scratch)");
   if (hipMalloc(&vp->d_primes, kMaxPrimes * sizeof(PrimeDev)) != hipSuccess) return bail("hipMalloc(primes)");
+#ifdef ALOHA_EXPERIMENTS
   if (hipMalloc(&vp->d_fused_status, 4) != hipSuccess) return bail("hipMalloc(status)");
   if (hipMemsetAsync(vp->d_fused_status, 0, 4, vp->stream) != hipSuccess) return bail("memset");
+#endif
   // the RTL's memories power up as X; give them a defined 0 instead
   if (hipMemsetAsync(vp->d_spm, 0, (vp->spm_rows ? vp->spm_rows : 1) * (size_t)ALOHA_ROW_BYTES, vp->stream) != hipSuccess) return bail("memset");
   if (hipMemsetAsync(vp->d_ksk, 0, (vp->ksk_rows ? vp->ksk_rows : 1) * (size_t)ALOHA_ROW_BYTES, vp->stream) != hipSuccess) return bail("memset");
@@ -569,7 +590,9 @@ void aloha_vp_destroy(aloha_vp *vp) {
   vp->plans.clear();
   for (auto &b : vp->blobs) if (b.second) (void)hipFree(b.second);
   for (auto &e : vp->enc_tables) if (e.second.alloc) (void)hipFree(e.second.alloc);
+#ifdef ALOHA_EXPERIMENTS
   if (vp->d_fused_status) (void)hipFree(vp->d_fused_status);
+#endif
   if (vp->d_enc_in) (void)hipFree(vp->d_enc_in);
   if (vp->d_enc_work) (void)hipFree(vp->d_enc_work);
   if (vp->own_stream && vp->stream) (void)hipStreamDestroy(vp->stream);
@@ -754,16 +777,18 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       auto mix = [&](uint64_t x) { h = (h ^ x) * 0x100000001b3ull; };
       for (uint32_t i = pc; i <= end; i++) { mix(vp->inst[i]); mix(vp->imm[i]); }
       for (int i = 0; i < 4; i++) mix(csr[i]);
-      mix(step); mix(vp->vl_bits); mix(vp->q); mix(vp->mu); mix(pc);
+      mix(step); mix(vp->vl_bits); mix(vp->q); mix(vp->mu); mix(pc); mix(vp->scratch_row); mix(vp->scratch_rows);
       run_hash = h;
       auto range = vp->run_cache.equal_range(h);
       for (auto it = range.first; it != range.second; ++it) {
         aloha_vp::RunPlan &pl = it->second;
         if (pl.epoch != vp->epoch || pl.pc != pc || pl.inst.size() != len || pl.step != step || pl.vl_in != vp->vl_bits ||
             pl.q_in != vp->q || pl.mu_in != vp->mu || memcmp(pl.csr, csr, sizeof csr) != 0 ||
+            pl.scratch_row != vp->scratch_row || pl.scratch_rows != vp->scratch_rows ||
             memcmp(pl.inst.data(), &vp->inst[pc], len * sizeof(uint32_t)) != 0 ||
             memcmp(pl.imm.data(), &vp->imm[pc], len * sizeof(uint64_t)) != 0)
           continue;
+#ifdef ALOHA_EXPERIMENTS
         if (vp->graphs_on && !pl.graph && !pl.graph_failed && ++pl.replays >= 2 && !vp->fused_stats) {
           // capture the list once; a failure (an op that cannot be captured) leaves it a list for good
           const uint64_t l0 = vp->stats.kernel_launches, f0 = vp->stats.fused_launches;
@@ -785,7 +810,9 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "graph launch of a recorded run failed: %s", hipGetErrorString(e));
           vp->stats.kernel_launches += pl.launches;
           vp->stats.graph_launches++;
-        } else {
+        } else
+#endif
+        {
           for (const auto &op : pl.ops) {
             const hipError_t e = op();
             if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "replayed launch failed: %s", hipGetErrorString(e));
@@ -799,6 +826,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       fresh.imm.assign(vp->imm.begin() + pc, vp->imm.begin() + end + 1);
       memcpy(fresh.csr, csr, sizeof csr);
       fresh.step = step; fresh.vl_in = vp->vl_bits; fresh.q_in = vp->q; fresh.mu_in = vp->mu; fresh.pc = pc;
+      fresh.scratch_row = vp->scratch_row; fresh.scratch_rows = vp->scratch_rows;
       vp->rec = &fresh;
     }
   }
@@ -866,9 +894,363 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   uint64_t lazy_q[ALOHA_NVREG] = {0};
 
   auto rd = [&](unsigned r) -> const u64 * { return alias[r] ? alias[r] : vreg(vp, r); };
+  // Sums stored to memory, launched together.  Jobs that are sums of scaled operands over the SAME operands (a basis
+  // conversion: one digit under every target modulus) leave as groups -- the operands are read once per element instead of
+  // once per output.
+  auto launch_dots = [&](const std::vector<aloha::k::DotArgs> &jobs, unsigned lg) -> aloha_status {
+    aloha_status s = ALOHA_OK;
+    if (jobs.empty()) return s;
+    std::vector<aloha::k::SumGroup> groups;
+    std::vector<aloha::k::SumJob> sjobs;
+    std::vector<aloha::k::DotArgs> rest;
+    if (fuse && jobs.size() >= 4) {
+      std::map<std::array<const u64 *, aloha::k::kSumTerms>, std::vector<size_t>> by_ops;
+      std::vector<char> grouped(jobs.size(), 0);
+      for (size_t i = 0; i < jobs.size(); i++) {
+        const auto &g = jobs[i];
+        std::array<const u64 *, aloha::k::kSumTerms> key{};
+        int nv = 0;
+        bool ok = !g.init;
+        for (int t = 0; ok && t < g.nterms; t++) {
+          if (g.b[t]) ok = false;                                 // a vector x vector term
+          else if (g.a[t]) { if (nv == aloha::k::kSumTerms) ok = false; else key[nv++] = g.a[t]; }
+        }
+        if (ok && nv) by_ops[key].push_back(i);
+      }
+      for (const auto &kv : by_ops) {
+        if (kv.second.size() < 4) continue;
+        // a group's outputs are a serial loop inside one thread: at most kPerGroup of them per group, so that
+        // there are enough workgroups in flight (the operands are then re-read once per sub-group, from L2)
+        constexpr size_t kPerGroup = 4;
+        for (size_t j0 = 0; j0 < kv.second.size(); j0 += kPerGroup) {
+          aloha::k::SumGroup sg{};
+          int nv = 0;
+          while (nv < aloha::k::kSumTerms && kv.first[nv]) { sg.a[nv] = kv.first[nv]; nv++; }
+          sg.nterms = nv; sg.first = (uint32_t)sjobs.size();
+          sg.count = (uint32_t)std::min(kPerGroup, kv.second.size() - j0);
+          for (size_t jj = j0; jj < j0 + sg.count; jj++) {
+            const size_t i = kv.second[jj];
+            const auto &g = jobs[i];
+            aloha::k::SumJob sj{};
+            int v = 0;
+            for (int t = 0; t < g.nterms; t++) {
+              if (g.a[t]) { sj.s[v] = g.s[t]; sj.sp[v] = g.sp[t]; v++; }
+              else { sj.cst += g.s[t]; if (sj.cst >= g.m.q) sj.cst -= g.m.q; }
+            }
+            sj.d = g.d; sj.m = g.m;
+            sjobs.push_back(sj);
+            grouped[i] = 1;
+          }
+          groups.push_back(sg);
+        }
+      }
+      if (!groups.empty())
+        for (size_t i = 0; i < jobs.size(); i++) if (!grouped[i]) rest.push_back(jobs[i]);
+    }
+    const std::vector<aloha::k::DotArgs> &plain = groups.empty() ? jobs : rest;
+    if (!groups.empty()) {
+      // one blob: groups first, then jobs (device_blob hands out one region per call)
+      std::vector<unsigned char> blob(groups.size() * sizeof(groups[0]) + sjobs.size() * sizeof(sjobs[0]));
+      memcpy(blob.data(), groups.data(), groups.size() * sizeof(groups[0]));
+      memcpy(blob.data() + groups.size() * sizeof(groups[0]), sjobs.data(), sjobs.size() * sizeof(sjobs[0]));
+      const void *dg = nullptr;
+      s = device_blob(vp, blob.data(), blob.size(), &dg);
+      if (!s) {
+        const uint32_t ng = (uint32_t)groups.size(), nn = 1u << lg;
+        const aloha::k::SumJob *djobs = (const aloha::k::SumJob *)((const unsigned char *)dg + groups.size() * sizeof(groups[0]));
+        hipError_t e = issue(vp, [=]() -> hipError_t {
+          vp->stats.kernel_launches++;
+          return aloha::k::sum_groups(st, (const aloha::k::SumGroup *)dg, ng, djobs, nn);
+        });
+        if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "sum_groups: %s", hipGetErrorString(e));
+      }
+    }
+    if (!s && !plain.empty()) {
+      const void *dj = nullptr;
+      s = device_blob(vp, plain.data(), plain.size() * sizeof(plain[0]), &dj);
+      if (!s) {
+        const uint32_t nj = (uint32_t)plain.size(), nn = 1u << lg;
+        hipError_t e = issue(vp, [=]() -> hipError_t {
+          vp->stats.kernel_launches++;
+          return aloha::k::dot_batch(st, (const aloha::k::DotArgs *)dj, nj, nn);
+        });
+        if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "dot_batch: %s", hipGetErrorString(e));
+      }
+    }
+    return s;
+  };
+  // ---- staged batches (the fused key-switch phases at N = 2^16) ------------------------------------------------------------
+  // A phase program is a chain  sums -> forward transforms -> sums  (keyswitch.mem:9-14 -> :10,:14 -> :46-79, and
+  // :86-91 -> :94-99 -> :102-117).  Instead of launching a batch when a job of another kind arrives, a batch of sums that
+  // is followed by forward transforms is HELD (stage 0), and so is the batch of transforms when sums follow it (stage 1):
+  // stages keep program order, so holding changes nothing by itself.  At the flush the stages are matched:
+  //   * a sum whose store is overwritten by the in-place transform of the same rows becomes the column pass's input
+  //     (SumSrc: never materialised -- exact, the store was dead);
+  //   * inner products  sum_d X_d .* KEY_{d,c}  over transformed limbs X_d become the row pass's output (RowDotGroup), and
+  //     a sum of scaled operands with ONE transformed limb among them the row pass's epilogue (RowEpi).  The transformed
+  //     limbs themselves are still stored, unless they lie in the caller's scratch window (aloha_vp_set_scratch) and no
+  //     later instruction of the run loads them.
+  // Anything that does not match is launched as before, in stage order.
+  std::vector<aloha::k::DotArgs> held_sums;
+  std::vector<LimbJob> held_ntt;
+  auto in_scratch = [&](const u64 *p_, size_t n_) {
+    const u64 *lo = vp->d_spm + vp->scratch_row * kLanes, *hi = lo + vp->scratch_rows * kLanes;
+    return vp->scratch_rows && p_ >= lo && p_ + n_ <= hi;
+  };
+  // are rows of [p_, p_ + n_) still to be read -- through a register that aliases them, a lazy sum over them, or a load by
+  // the instruction being sequenced (pc) or a later one?
+  auto loaded_later = [&](const u64 *p_, uint32_t n_) {
+    for (unsigned r = 0; r < ALOHA_NVREG; r++) {
+      bool refers = alias[r] && overlap(alias[r], p_, n_);
+      for (const auto &t : lazy[r]) refers = refers || (t.first && overlap(t.first, p_, n_)) || (t.second && overlap(t.second, p_, n_));
+      if (refers && !dead_from(vp, pc, r)) return true;
+    }
+    for (uint32_t i = pc; i < ALOHA_IRAM_DEPTH; i++) {
+      const Decoded d = decode_at(vp, i);
+      if (d.funct6 == 0x10) return false;
+      if (d.funct6 == 0x04) return true;                      // the vector length changes: not followed further
+      if (d.funct6 != 0x03) continue;
+      const u64 *r = mem_rows(vp, d.imm, true, csr, n_ / kLanes);
+      if (r && overlap(r, p_, n_)) return true;
+    }
+    return true;
+  };
+  auto launch_staged = [&]() -> aloha_status {
+    std::vector<aloha::k::DotArgs> S, D;
+    std::vector<LimbJob> T;
+    S.swap(held_sums);
+    if (!held_ntt.empty()) {
+      T.swap(held_ntt);
+      if (pend_kind == PK_DOT) D.swap(dot_batch);
+    } else if (pend_kind == PK_NTT && !batch_inv) {
+      T.swap(batch);
+    }
+    const unsigned lg = batch_logn;
+    const uint32_t nn = 1u << lg;
+    const size_t nT = T.size();
+    aloha_status s = ALOHA_OK;
+    // Fusing moves work in time: a fused sum reads its operands while the transforms run, a fused inner product or
+    // epilogue reads its operands and writes its result while the transforms run.  Besides the one intended dependency
+    // nothing of the transforms' batch may touch those rows.
+    auto t_writes = [&](const u64 *p_, const u64 *except) {
+      for (const LimbJob &j : T) if (j.dst != except && overlap(p_, j.dst, nn)) return true;
+      return false;
+    };
+    auto t_touches = [&](const u64 *p_) {
+      for (const LimbJob &j : T) if (overlap(p_, j.dst, nn) || overlap(p_, j.src, nn)) return true;
+      return false;
+    };
+    // -- stage 0 -> 1: sums that only feed an in-place transform ------------------------------------------------------------
+    std::vector<int> pro_of(nT, -1);
+    std::vector<char> s_used(S.size(), 0);
+    bool any = false;
+    if (nT && lg == 16 && !S.empty()) {
+      std::unordered_map<const u64 *, size_t> by_dst;
+      for (size_t i = 0; i < S.size(); i++) by_dst[S[i].d] = i;
+      for (size_t t = 0; t < nT; t++) {
+        if (T[t].src != T[t].dst) continue;
+        auto it = by_dst.find(T[t].src);
+        if (it == by_dst.end()) continue;
+        const auto &g = S[it->second];
+        int nv = 0;
+        bool ok = !g.init && g.m.q == vp->slots[T[t].prime].q;
+        for (int k = 0; ok && k < g.nterms; k++) {
+          if (g.b[k]) ok = false;
+          else if (g.a[k]) ok = ++nv <= aloha::k::kSumTerms && !t_writes(g.a[k], nullptr);
+        }
+        if (!ok || !nv) continue;
+        pro_of[t] = (int)it->second; s_used[it->second] = 1; any = true;
+      }
+    }
+    // -- stage 1 -> 2: sums over transformed limbs -------------------------------------------------------------------------
+    std::vector<int> t_use(nT, 0), epi_of(nT, -1);             // t_use: 1 = digit of an inner product, 2 = carries an epilogue
+    std::vector<char> d_fused(D.size(), 0);
+    struct Cand { std::vector<const u64 *> x, key; };
+    std::vector<Cand> cand(D.size());
+    std::map<std::vector<const u64 *>, std::vector<size_t>> dgroups;
+    if (nT && lg == 16 && !D.empty()) {
+      std::unordered_map<const u64 *, size_t> t_by_dst;
+      for (size_t t = 0; t < nT; t++) t_by_dst[T[t].dst] = t;
+      bool ok = true;
+      for (size_t i = 0; i < D.size() && ok; i++) {
+        const auto &g = D[i];
+        int n_t = 0, nvv = 0, nsc = 0;
+        for (int k = 0; k < g.nterms; k++) {
+          n_t += (g.a[k] && t_by_dst.count(g.a[k])) + (g.b[k] && t_by_dst.count(g.b[k]));
+          if (g.a[k] && g.b[k]) nvv++; else if (g.a[k]) nsc++;
+        }
+        if (!n_t) continue;                                      // does not read a transformed limb: an ordinary sum behind the transforms
+        if (g.init || t_touches(g.d)) { ok = false; break; }
+        for (int k = 0; k < g.nterms && ok; k++)                 // operands that merely overlap a transform's output
+          for (const u64 *o : {g.a[k], g.b[k]}) if (o && !t_by_dst.count(o) && t_writes(o, nullptr)) ok = false;
+        if (!ok) break;
+        if (nvv == g.nterms && g.nterms <= aloha::k::kRowDotMax) {
+          Cand &c = cand[i];
+          for (int k = 0; k < g.nterms && ok; k++) {
+            const bool at = t_by_dst.count(g.a[k]) != 0, bt = t_by_dst.count(g.b[k]) != 0;
+            if (at && bt) ok = false;
+            else if (bt) { c.x.push_back(g.b[k]); c.key.push_back(g.a[k]); }
+            else { c.x.push_back(g.a[k]); c.key.push_back(g.b[k]); }
+          }
+          if (ok) dgroups[c.x].push_back(i);
+        } else if (!nvv && n_t == 1 && nsc <= aloha::k::kEpiOps + 1) {
+          size_t tt = 0;
+          for (int k = 0; k < g.nterms; k++) if (g.a[k] && t_by_dst.count(g.a[k])) tt = t_by_dst[g.a[k]];
+          if (t_use[tt] || g.m.q != vp->slots[T[tt].prime].q) ok = false;
+          else { t_use[tt] = 2; epi_of[tt] = (int)i; d_fused[i] = 1; }
+        } else ok = false;
+      }
+      for (auto &kv : dgroups) {
+        if (!ok) break;
+        if (kv.second.size() != 2 || D[kv.second[0]].m.q != D[kv.second[1]].m.q) { ok = false; break; }
+        for (const u64 *x : kv.first) {
+          auto it = t_by_dst.find(x);
+          if (it == t_by_dst.end()) continue;
+          if (t_use[it->second] || vp->slots[T[it->second].prime].q != D[kv.second[0]].m.q) { ok = false; break; }
+          t_use[it->second] = 1;
+        }
+        if (ok) for (size_t i : kv.second) d_fused[i] = 1;
+      }
+      if (!ok) {                                                 // something reads a transformed limb in a way the kernels do not cover
+        std::fill(t_use.begin(), t_use.end(), 0); std::fill(epi_of.begin(), epi_of.end(), -1);
+        std::fill(d_fused.begin(), d_fused.end(), 0); dgroups.clear();
+      } else if (!dgroups.empty() || std::count(t_use.begin(), t_use.end(), 2)) any = true;
+    }
+    if (!any) {                                                  // nothing to fuse: the stages as separate batches
+      s = launch_dots(S, lg);
+      if (!s && nT) s = run_transforms(vp, T, lg, false);
+      if (!s) s = launch_dots(D, lg);
+      return s;
+    }
+    {
+      std::vector<aloha::k::DotArgs> rest;
+      for (size_t i = 0; i < S.size(); i++) if (!s_used[i]) rest.push_back(S[i]);
+      s = launch_dots(rest, lg);
+      if (s) return s;
+    }
+    // limbs of inner products first (column pass only), the others behind them (column pass + row tiles)
+    std::vector<size_t> order;
+    for (size_t t = 0; t < nT; t++) if (t_use[t] == 1) order.push_back(t);
+    const uint32_t n_dot = (uint32_t)order.size();
+    if (n_dot >= 16) {
+      // Their order is free (their row pass walks descriptors, not a tile list).  Limbs whose sums share operands -- one
+      // digit lifted to many moduli -- are dealt out so that one XCD works through them back to back: the column
+      // kernel maps limb 8s + x to XCD x (a placement observed, not promised: it only matters for speed), and the
+      // operands of <= 2 digits (2 MiB each at N = 2^16, alpha = 4) then stay in that XCD's 4 MiB L2 instead of being
+      // fetched again for every limb.
+      auto key_of = [&](size_t t) {
+        std::array<const u64 *, aloha::k::kSumTerms> key{};
+        if (pro_of[t] >= 0) {
+          const auto &g = S[pro_of[t]];
+          int nv = 0;
+          for (int k = 0; k < g.nterms; k++) if (g.a[k]) key[nv++] = g.a[k];
+        }
+        return key;
+      };
+      std::vector<size_t> rd(order);
+      std::stable_sort(rd.begin(), rd.end(), [&](size_t a, size_t b) { return key_of(a) < key_of(b); });
+      const size_t full = n_dot / 8 * 8, per = full / 8;
+      for (size_t p = 0; p < full; p++) order[(p % per) * 8 + p / per] = rd[p];
+      for (size_t p = full; p < n_dot; p++) order[p] = rd[p];
+    }
+    for (size_t t = 0; t < nT; t++) if (t_use[t] != 1) order.push_back(t);
+    std::vector<size_t> pos_of(nT);
+    for (size_t i = 0; i < nT; i++) pos_of[order[i]] = i;
+    std::vector<LimbJob> J(2 * nT);
+    std::vector<aloha::k::SumSrc> sums;
+    std::vector<aloha::k::RowEpi> epis;
+    for (size_t i = 0; i < nT; i++) {
+      const size_t t = order[i];
+      LimbJob jb = T[t];
+      if (pro_of[t] >= 0) {
+        const auto &g = S[pro_of[t]];
+        aloha::k::SumSrc ss{};
+        for (int k = 0; k < g.nterms; k++) {
+          if (g.a[k]) { ss.a[ss.nterms] = g.a[k]; ss.s[ss.nterms] = g.s[k]; ss.sp[ss.nterms] = g.sp[k]; ss.nterms++; }
+          else { ss.cst += g.s[k]; if (ss.cst >= g.m.q) ss.cst -= g.m.q; }
+        }
+        sums.push_back(ss);
+        jb.pro = (uint32_t)sums.size();
+      }
+      if (epi_of[t] >= 0) {
+        const auto &g = D[epi_of[t]];
+        aloha::k::RowEpi e{};
+        for (int k = 0; k < g.nterms; k++) {
+          if (g.a[k] == jb.dst) { e.s[0] = g.s[k]; e.sp[0] = g.sp[k]; }
+          else if (g.a[k]) { e.a[e.nops] = g.a[k]; e.s[e.nops + 1] = g.s[k]; e.sp[e.nops + 1] = g.sp[k]; e.nops++; }
+          else { e.cst += g.s[k]; if (e.cst >= g.m.q) e.cst -= g.m.q; }
+        }
+        e.out = g.d;
+        e.store_t = (in_scratch(jb.dst, nn) && !loaded_later(jb.dst, nn)) ? 0 : 1;
+        epis.push_back(e);
+        jb.epi = (uint32_t)epis.size();
+      }
+      J[i] = jb;
+      J[nT + i] = jb; J[nT + i].src = jb.dst;
+    }
+    std::vector<aloha::k::RowDotGroup> rgroups;
+    for (const auto &kv : dgroups) {
+      const Cand &c0 = cand[kv.second[0]], &c1 = cand[kv.second[1]];
+      aloha::k::RowDotGroup rg{};
+      std::unordered_map<const u64 *, size_t> t_by_dst;
+      for (size_t t = 0; t < nT; t++) if (t_use[t] == 1) t_by_dst[T[t].dst] = t;
+      for (int pass = 0; pass < 2; pass++)                        // transformed digits first, then the ones in NTT form already
+        for (size_t k = 0; k < c0.x.size(); k++) {
+          const bool is_t = t_by_dst.count(c0.x[k]) != 0;
+          if (is_t != (pass == 0)) continue;
+          const uint32_t d = rg.nt + rg.np;
+          rg.x[d] = c0.x[k]; rg.key[d][0] = c0.key[k]; rg.key[d][1] = c1.key[k];
+          if (is_t) {
+            rg.prime = T[t_by_dst[c0.x[k]]].prime;
+            rg.xout[d] = (in_scratch(c0.x[k], nn) && !loaded_later(c0.x[k], nn)) ? nullptr : const_cast<u64 *>(c0.x[k]);
+            rg.nt++;
+          } else rg.np++;
+        }
+      rg.out[0] = D[kv.second[0]].d; rg.out[1] = D[kv.second[1]].d;
+      rgroups.push_back(rg);
+    }
+    std::vector<TileDesc> uni, glb;
+    if (nT > n_dot) aloha::k::build_row_tiles(J.data() + nT, n_dot, (uint32_t)nT - n_dot, lg - 8, uni, glb);
+    std::vector<TileDesc> tiles(uni);
+    tiles.insert(tiles.end(), glb.begin(), glb.end());
+    const void *dJ = nullptr, *dS = nullptr, *dE = nullptr, *dG = nullptr, *dT = nullptr;
+    s = device_blob(vp, J.data(), J.size() * sizeof(J[0]), &dJ);
+    if (!s && !sums.empty()) s = device_blob(vp, sums.data(), sums.size() * sizeof(sums[0]), &dS);
+    if (!s && !epis.empty()) s = device_blob(vp, epis.data(), epis.size() * sizeof(epis[0]), &dE);
+    if (!s && !rgroups.empty()) s = device_blob(vp, rgroups.data(), rgroups.size() * sizeof(rgroups[0]), &dG);
+    if (!s && !tiles.empty()) s = device_blob(vp, tiles.data(), tiles.size() * sizeof(tiles[0]), &dT);
+    if (s) return s;
+    {
+      const uint32_t cnt = (uint32_t)nT, n_uni = (uint32_t)uni.size(), n_glb = (uint32_t)glb.size(), n_grp = (uint32_t)rgroups.size();
+      const hipError_t e = issue(vp, [=]() -> hipError_t {
+        uint64_t launches = 0;
+        const LimbJob *dj = (const LimbJob *)dJ;
+        const TileDesc *dt = (const TileDesc *)dT;
+        hipError_t e = aloha::k::ntt_fwd16_cols(st, dj, vp->d_primes, cnt, (const aloha::k::SumSrc *)dS, &launches);
+        if (e == hipSuccess) e = aloha::k::ntt_fwd16_rows(st, dj + cnt, vp->d_primes, dt, n_uni, dt + n_uni, n_glb, (const aloha::k::RowEpi *)dE, &launches);
+        if (e == hipSuccess) e = aloha::k::ntt_fwd16_rowdot(st, (const aloha::k::RowDotGroup *)dG, n_grp, vp->d_primes, &launches);
+        vp->stats.kernel_launches += launches;
+        vp->stats.ks_fused_launches += launches;
+        return e;
+      });
+      if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "fused key-switch transforms: %s", hipGetErrorString(e));
+    }
+    std::vector<aloha::k::DotArgs> rest;
+    for (size_t i = 0; i < D.size(); i++) if (!d_fused[i]) rest.push_back(D[i]);
+    return launch_dots(rest, lg);
+  };
+  auto reset_pending = [&]() {
+    pend_rw.clear();
+    box_r_lo = box_r_hi = box_w_lo = box_w_hi = nullptr;
+    dot_w_lo = dot_w_hi = dot_a_lo = dot_a_hi = dot_b_lo = dot_b_hi = nullptr;
+    pend_kind = PK_NONE;
+  };
+  const bool stage_ok = fuse && !(vp->flags & ALOHA_FLAG_RADIX2_ONLY) && !getenv("ALOHA_NO_STAGES");   // (the variable: A/B timing switch)
   auto flush = [&]() -> aloha_status {
     aloha_status s = ALOHA_OK;
-    if (pend_kind == PK_NTT && !batch.empty()) {
+    if (!held_sums.empty() || !held_ntt.empty()) s = launch_staged();       // (takes the pending batch with it when that is the next stage)
+    if (s) {
+    } else if (pend_kind == PK_NTT && !batch.empty()) {
       s = run_transforms(vp, batch, batch_logn, batch_inv);
     } else if (pend_kind == PK_AUT && !aut_batch.empty()) {
       const void *dj = nullptr;
@@ -897,85 +1279,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       }
     }
     else if (pend_kind == PK_DOT && !dot_batch.empty()) {
-      // Jobs that are sums of scaled operands over the SAME operands (a basis conversion: one digit under every
-      // target modulus) leave as groups -- the operands are read once per element instead of once per output.
-      std::vector<aloha::k::SumGroup> groups;
-      std::vector<aloha::k::SumJob> sjobs;
-      std::vector<aloha::k::DotArgs> rest;
-      if (fuse && dot_batch.size() >= 4) {
-        std::map<std::array<const u64 *, aloha::k::kSumTerms>, std::vector<size_t>> by_ops;
-        std::vector<char> grouped(dot_batch.size(), 0);
-        for (size_t i = 0; i < dot_batch.size(); i++) {
-          const auto &g = dot_batch[i];
-          std::array<const u64 *, aloha::k::kSumTerms> key{};
-          int nv = 0;
-          bool ok = !g.init;
-          for (int t = 0; ok && t < g.nterms; t++) {
-            if (g.b[t]) ok = false;                                 // a vector x vector term
-            else if (g.a[t]) { if (nv == aloha::k::kSumTerms) ok = false; else key[nv++] = g.a[t]; }
-          }
-          if (ok && nv) by_ops[key].push_back(i);
-        }
-        for (const auto &kv : by_ops) {
-          if (kv.second.size() < 4) continue;
-          // a group's outputs are a serial loop inside one thread: at most kPerGroup of them per group, so that
-          // there are enough workgroups in flight (the operands are then re-read once per sub-group, from L2)
-          constexpr size_t kPerGroup = 4;
-          for (size_t j0 = 0; j0 < kv.second.size(); j0 += kPerGroup) {
-            aloha::k::SumGroup sg{};
-            int nv = 0;
-            while (nv < aloha::k::kSumTerms && kv.first[nv]) { sg.a[nv] = kv.first[nv]; nv++; }
-            sg.nterms = nv; sg.first = (uint32_t)sjobs.size();
-            sg.count = (uint32_t)std::min(kPerGroup, kv.second.size() - j0);
-            for (size_t jj = j0; jj < j0 + sg.count; jj++) {
-              const size_t i = kv.second[jj];
-              const auto &g = dot_batch[i];
-              aloha::k::SumJob sj{};
-              int v = 0;
-              for (int t = 0; t < g.nterms; t++) {
-                if (g.a[t]) { sj.s[v] = g.s[t]; sj.sp[v] = g.sp[t]; v++; }
-                else { sj.cst += g.s[t]; if (sj.cst >= g.m.q) sj.cst -= g.m.q; }
-              }
-              sj.d = g.d; sj.m = g.m;
-              sjobs.push_back(sj);
-              grouped[i] = 1;
-            }
-            groups.push_back(sg);
-          }
-        }
-        if (!groups.empty())
-          for (size_t i = 0; i < dot_batch.size(); i++) if (!grouped[i]) rest.push_back(dot_batch[i]);
-      }
-      const std::vector<aloha::k::DotArgs> &plain = groups.empty() ? dot_batch : rest;
-      if (!groups.empty()) {
-        // one blob: groups first, then jobs (device_blob hands out one region per call)
-        std::vector<unsigned char> blob(groups.size() * sizeof(groups[0]) + sjobs.size() * sizeof(sjobs[0]));
-        memcpy(blob.data(), groups.data(), groups.size() * sizeof(groups[0]));
-        memcpy(blob.data() + groups.size() * sizeof(groups[0]), sjobs.data(), sjobs.size() * sizeof(sjobs[0]));
-        const void *dg = nullptr;
-        s = device_blob(vp, blob.data(), blob.size(), &dg);
-        if (!s) {
-          const uint32_t ng = (uint32_t)groups.size(), nn = 1u << batch_logn;
-          const aloha::k::SumJob *djobs = (const aloha::k::SumJob *)((const unsigned char *)dg + groups.size() * sizeof(groups[0]));
-          hipError_t e = issue(vp, [=]() -> hipError_t {
-            vp->stats.kernel_launches++;
-            return aloha::k::sum_groups(st, (const aloha::k::SumGroup *)dg, ng, djobs, nn);
-          });
-          if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "sum_groups: %s", hipGetErrorString(e));
-        }
-      }
-      if (!s && !plain.empty()) {
-        const void *dj = nullptr;
-        s = device_blob(vp, plain.data(), plain.size() * sizeof(plain[0]), &dj);
-        if (!s) {
-          const uint32_t nj = (uint32_t)plain.size(), nn = 1u << batch_logn;
-          hipError_t e = issue(vp, [=]() -> hipError_t {
-            vp->stats.kernel_launches++;
-            return aloha::k::dot_batch(st, (const aloha::k::DotArgs *)dj, nj, nn);
-          });
-          if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "dot_batch: %s", hipGetErrorString(e));
-        }
-      }
+      s = launch_dots(dot_batch, batch_logn);
     }
     batch.clear(); aut_batch.clear(); ew_batch.clear(); dot_batch.clear(); pend_rw.clear();
     box_r_lo = box_r_hi = box_w_lo = box_w_hi = nullptr;
@@ -1298,6 +1602,12 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           // fused `vle; vntt; vse`: join the pending transform batch unless it conflicts with it
           // (an in-place job, src == z, is fine: can_join sees only OTHER jobs' ranges)
           auto joinable = [&]() { return can_join(PK_NTT, logn, src, nullptr, z, n) && (batch.empty() || batch_inv == inv); };
+          // forward transforms at N = 2^16 behind a batch of sums: the sums are held, not launched (staged batches, above)
+          if (stage_ok && !inv && logn == 16 && pend_kind == PK_DOT && batch_logn == 16 && !dot_batch.empty() && held_sums.empty() &&
+              held_ntt.empty()) {
+            held_sums.swap(dot_batch);
+            reset_pending();
+          }
           if (!joinable()) ALOHA_RUN_CK(flush());
           if (alias[vs1] == src && dead_from(vp, pc + 2 + skip, vs1)) alias[vs1] = nullptr;   // (undefined after the transform anyway)
           ALOHA_RUN_CK(before_mem_write(z, n, pc + 2 + skip));
@@ -1365,6 +1675,11 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
                 }
                 return true;
               };
+              // a sum behind a batch of forward transforms at N = 2^16: the transforms are held (staged batches, above)
+              if (stage_ok && logn == 16 && pend_kind == PK_NTT && !batch_inv && batch_logn == 16 && !batch.empty() && held_ntt.empty()) {
+                held_ntt.swap(batch);
+                reset_pending();
+              }
               if (!joinable()) ALOHA_RUN_CK(flush());
               aloha::k::DotArgs g{};
               g.nterms = (int)lazy[vs1].size();

@@ -23,6 +23,11 @@ parity is against the oracle's ISA machine plus decryption semantics (tests/ckks
     phase 4      t_c[j] = NTT_j( sum_k W[k][c] * (P/p_k mod q_j) - floor(P/2) );
                  r_c[j] = (acc_c[j] - t_c[j]) * P^-1 mod q_j;   out = (ROT + r_0, [BASE1 +] r_1)
 
+THE PROGRAMS COME FROM ONE GENERATOR: the C host (csrc/keyswitch_host.cpp, ``aloha_ks_program``).  This module holds the
+slot layout (``HybridLayout``, what a Python caller needs to place and fetch data) and a driver that fetches the phase
+programs from a C plan and runs them on any engine with the VP call surface -- the GPU engine, or the oracle's ISA
+machine in the parity tests, which therefore execute word for word what the C host executes.
+
 Everything is HE-ISA: the ModUp / ModDown sums are ``vfqmul.vs`` / ``vfqadd.vv`` chains over memory
 operands, which the engine's fusing sequencer evaluates as one pass per output limb and one
 launch per program (scalar lazy terms), exactly like the digit-by-key products.  The basis
@@ -53,7 +58,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import isa
-from .keyswitch import Exchange, LANES, SPM, KSK, _setq, owner
+from .keyswitch import Exchange, LANES, SPM, KSK, owner
 
 
 def _prod(xs):
@@ -157,249 +162,6 @@ class HybridLayout:
         return self.Mr * self.dnum * 2
 
 
-def _inv(a: int, q: int) -> int:
-    return pow(a % q, q - 2, q)
-
-
-def _pack(blocks: Sequence[Sequence[str]], n: int) -> List[List[str]]:
-    """Greedy packing of instruction blocks into programs that fit the 4096-word ROM."""
-    progs, cur = [], [f"vsetvl {64 * n:#x}"]
-    for b in blocks:
-        if len(b) + 2 > isa.IRAM_DEPTH:
-            raise ValueError("one block exceeds the instruction ROM")
-        if len(cur) + len(b) + 1 > isa.IRAM_DEPTH:
-            progs.append(cur + ["break"])
-            cur = [f"vsetvl {64 * n:#x}"]
-        cur += list(b)
-    progs.append(cur + ["break"])
-    return progs
-
-
-def _scalar_sum(srcs: Sequence[int], scalars: Sequence[int], dst_off: int, minus: Optional[int] = None,
-                plus: Optional[int] = None) -> List[str]:
-    """dst = sum_t mem[srcs[t]] * scalars[t] [- minus] [+ plus] under the current modulus, as a foldable chain
-    (the engine evaluates it in one pass over its operands)."""
-    out = []
-    for t, (s, c) in enumerate(zip(srcs, scalars)):
-        if t == 0:
-            out += [f"vle v0, abs+{s:#x}", f"vfqmul.vs v6, v0, {c:#x}"]
-        else:
-            out += [f"vle v0, abs+{s:#x}", f"vfqmul.vs v3, v0, {c:#x}", "vfqadd.vv v6, v6, v3"]
-    if minus is not None:
-        out.append(f"vfqsub.vs v6, v6, {minus:#x}")
-    if plus is not None:
-        out.append(f"vfqadd.vs v6, v6, {plus:#x}")
-    return out + [f"vse v6, abs+{dst_off:#x}"]
-
-
-def blocks_phase1(lo: HybridLayout, mode: str, bs=None) -> List[List[str]]:
-    b, o, B = [], lo.off, (range(lo.B) if bs is None else bs)
-    own = list(enumerate(lo.owned_ct))
-    if mode == "rotate":
-        for i, j in own:                                        # NTT-domain automorphism of both components
-            for bi in B:
-                b.append(_setq(lo.moduli[j]) + [
-                    f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{o(lo.s_rot(i, bi)):#x}",
-                    f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{o(lo.s_x(i, bi)):#x}"])
-    elif mode == "multiply":                                    # tensor product
-        for i, j in own:
-            for bi in B:
-                b.append(_setq(lo.moduli[j]) + [
-                    f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(0, i, bi)):#x}", "vfqmul.vv v2, v0, v1",
-                    f"vse v2, abs+{o(lo.s_rot(i, bi)):#x}",
-                    f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(1, i, bi)):#x}", "vfqmul.vv v2, v0, v1",
-                    f"vse v2, abs+{o(lo.s_x(i, bi)):#x}"])
-        for i, j in own:
-            for bi in B:
-                b.append(_setq(lo.moduli[j]) + [
-                    f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(1, i, bi)):#x}", "vfqmul.vv v6, v0, v1",
-                    f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", f"vle v1, abs+{o(lo.s_inb(0, i, bi)):#x}", "vfqmul.vv v3, v0, v1",
-                    "vfqadd.vv v6, v6, v3", f"vse v6, abs+{o(lo.s_base1(i, bi)):#x}"])
-    if mode == "rotate_ref":
-        # alpha = 1 only: phase 1 exactly as the reference writes it (keyswitch.mem:4-7,:24-27,:100-121) -- inverse
-        # transforms, vaut in the coefficient domain, the rotated c0 back to NTT form -- so that a flipped zero reaches
-        # the basis extension as q_d, as in the RTL (vxu_lane.sv:598).  X (the digit under its own modulus) is the
-        # NTT of the rotated c1, word for word what vautn gives.
-        assert lo.alpha == 1
-        for i, j in own:
-            for bi in B:
-                b.append(_setq(lo.moduli[j]) + [
-                    f"vle v0, abs+{o(lo.s_in(0, i, bi)):#x}", "vintt v2, v0", f"vse v2, abs+{o(lo.s_s1(0, i, bi)):#x}",
-                    f"vle v0, abs+{o(lo.s_in(1, i, bi)):#x}", "vintt v2, v0", f"vse v2, abs+{o(lo.s_s1(1, i, bi)):#x}"])
-        for i, j in own:
-            for bi in B:
-                b.append(_setq(lo.moduli[j]) + [
-                    f"vle v0, abs+{o(lo.s_s1(1, i, bi)):#x}", "vaut v2, v0, 0x0", f"vse v2, abs+{o(lo.y_slot(j, bi)):#x}",
-                    f"vle v0, abs+{o(lo.s_s1(0, i, bi)):#x}", "vaut v2, v0, 0x0", f"vse v2, abs+{o(lo.s_s2(0, i, bi)):#x}"])
-        for i, j in own:
-            for bi in B:
-                b.append(_setq(lo.moduli[j]) + [
-                    f"vle v0, abs+{o(lo.s_s2(0, i, bi)):#x}", "vntt v2, v0", f"vse v2, abs+{o(lo.s_rot(i, bi)):#x}",
-                    f"vle v0, abs+{o(lo.y_slot(j, bi)):#x}", "vntt v2, v0", f"vse v2, abs+{o(lo.s_x(i, bi)):#x}"])
-        return b
-    x_of = (lambda i, bi: lo.s_in(1, i, bi)) if mode == "hoist" else lo.s_x    # hoisted: c1 itself, not rotated
-    for i, j in own:                                            # coefficient form, times (Q_d/q_j)^-1 mod q_j: one scaled
-        q = lo.moduli[j]                                        # inverse transform per limb (the engine folds the scalar
-        dig = lo.digit(j // lo.alpha)                           # into the transform's last stage)
-        c = _inv(_prod(lo.moduli[t] for t in dig if t != j), q)
-        blk = _setq(q)
-        for bi in B:
-            blk += [f"vle v0, abs+{o(x_of(i, bi)):#x}", "vintt v2, v0", f"vfqmul.vs v4, v2, {c:#x}", f"vse v4, abs+{o(lo.y_slot(j, bi)):#x}"]
-        b.append(blk)
-    return b
-
-
-def blocks_modup(lo: HybridLayout, bs=None) -> List[List[str]]:
-    b, o, B = [], lo.off, (range(lo.B) if bs is None else bs)
-    for jl, j in enumerate(lo.owned_all):                       # basis extension sums
-        m = lo.mods_all[j]
-        for d in range(lo.dnum):
-            dig = lo.digit(d)
-            if j in dig:
-                continue
-            scal = [_prod(lo.moduli[t] for t in dig if t != i) % m for i in dig]
-            for bi in B:
-                b.append(_setq(m) + _scalar_sum([o(lo.y_slot(i, bi)) for i in dig], scal, o(lo.s_sd(jl, d, bi))))
-    for jl, j in enumerate(lo.owned_all):                       # to NTT form, in place
-        m = lo.mods_all[j]
-        blk = _setq(m)
-        for d in range(lo.dnum):
-            if j in lo.digit(d):
-                continue
-            for bi in B:
-                s = o(lo.s_sd(jl, d, bi))
-                blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
-        b.append(blk)
-    return b
-
-
-def blocks_inner(lo: HybridLayout, hoisted: bool = False, regions=None) -> List[List[str]]:
-    """``regions`` (hoisted rotations in one pass): slot b is rotation b of the ONE decomposed ciphertext in slot 0,
-    with its key in key region ``regions[b]``."""
-    b, o = [], lo.off
-    x_of = (lambda i, bi: lo.s_in(1, i, bi)) if hoisted else lo.s_x
-    for jl, j in enumerate(lo.owned_all):
-        for bi in (range(lo.B) if regions is None else range(len(regions))):
-            blk = _setq(lo.mods_all[j])
-            sb = bi if regions is None else 0                 # operand slot
-            kb = 0 if regions is None else regions[bi] * lo.ksk_limbs
-            for c in range(2):
-                acc = 6 + 2 * c
-                for d in range(lo.dnum):
-                    src = o(x_of(lo.owned_ct.index(j), sb)) if j in lo.digit(d) else o(lo.s_sd(jl, d, sb))
-                    blk += [f"vle v0, abs+{src:#x}", f"vle v1, ksk+{(kb + (jl * lo.dnum + d) * 2 + c) * 8 * lo.n:#x}"]
-                    blk += [f"vfqmul.vv v{acc}, v0, v1"] if d == 0 else ["vfqmul.vv v3, v0, v1", f"vfqadd.vv v{acc}, v{acc}, v3"]
-                blk.append(f"vse v{acc}, abs+{o(lo.s_acc(jl, c, bi)):#x}")
-            b.append(blk)
-    return b
-
-
-def blocks_moddown_terms(lo: HybridLayout, bs=None) -> List[List[str]]:
-    """W = (iNTT(acc) + floor(P/2)) * (P/p_k)^-1 = iNTT(acc)*c + floor(P/2)*c: a transform, a scalar and a constant, which
-    the engine runs as one scaled inverse transform per accumulator (one batched launch pair for the phase)."""
-    b, o, B = [], lo.off, (range(lo.B) if bs is None else bs)
-    acc = lambda k, c, bi: o(lo.s_acc(lo.owned_all.index(lo.L + k), c, bi))
-    for k in lo.owned_sp:                                       # one scaled inverse transform per accumulator
-        p = lo.specials[k]
-        cinv = _inv(lo.P // p, p)
-        blk = _setq(p)
-        for c in range(2):
-            for bi in B:
-                blk += [f"vle v0, abs+{acc(k, c, bi):#x}", "vintt v2, v0", f"vfqmul.vs v4, v2, {cinv:#x}",
-                        f"vfqadd.vs v4, v4, {(lo.half % p) * cinv % p:#x}", f"vse v4, abs+{o(lo.w_slot(k, c, bi)):#x}"]
-        b.append(blk)
-    return b
-
-
-def blocks_finish(lo: HybridLayout, add_base1: bool, hoisted: bool = False, steps=None) -> List[List[str]]:
-    """t = sum_k W_k * (P/p_k mod q_j) - floor(P/2)  (one fused sum), NTT, then
-    out_c = acc_c * P^-1 + t_c * (-P^-1) + base_c  (one fused sum): two launches besides the transform.
-    ``hoisted``: base_0 is the unrotated c0 and the automorphism (vautn, CSR step) is applied to both results last.
-    ``steps``: slot b is rotation ``steps[b]`` of the ciphertext in slot 0 (the step rides in the instruction's immediate)."""
-    b, o, B = [], lo.off, (range(lo.B) if steps is None else range(len(steps)))
-    own = list(enumerate(lo.owned_ct))
-    for i, j in own:                                            # P-basis -> q_j, minus the rounding offset
-        q = lo.moduli[j]
-        for c in range(2):
-            for bi in B:
-                b.append(_setq(q) + _scalar_sum([o(lo.w_slot(k, c, bi)) for k in range(lo.K)],
-                                                [(lo.P // lo.specials[k]) % q for k in range(lo.K)], o(lo.s_s2(c, i, bi)), minus=lo.half % q))
-    for i, j in own:                                            # to NTT form (in place)
-        blk = _setq(lo.moduli[j])
-        for c in range(2):
-            for bi in B:
-                s = o(lo.s_s2(c, i, bi))
-                blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
-        b.append(blk)
-    for i, j in own:                                            # (acc - t) * P^-1 + base, as a sum of scaled operands
-        q = lo.moduli[j]
-        jl = lo.owned_all.index(j)
-        pinv = _inv(lo.P, q)
-        for c in range(2):
-            for bi in B:
-                srcs = [o(lo.s_acc(jl, c, bi)), o(lo.s_s2(c, i, bi))]
-                scal = [pinv, q - pinv]
-                if c == 0:
-                    srcs.append(o(lo.s_in(0, i, bi if steps is None else 0) if hoisted else lo.s_rot(i, bi))); scal.append(1)
-                elif add_base1:
-                    srcs.append(o(lo.s_base1(i, bi))); scal.append(1)
-                b.append(_setq(q) + _scalar_sum(srcs, scal, o(lo.s_s1(c, i, bi) if hoisted else lo.s_out(c, i, bi))))
-    if hoisted:
-        for i, j in own:
-            blk = _setq(lo.moduli[j])
-            for c in range(2):
-                for bi in B:
-                    blk += [f"vle v0, abs+{o(lo.s_s1(c, i, bi)):#x}", f"vautn v2, v0, {0 if steps is None else int(steps[bi]):#x}",
-                            f"vse v2, abs+{o(lo.s_out(c, i, bi)):#x}"]
-            b.append(blk)
-    return b
-
-
-def blocks_rescale(lo: HybridLayout) -> List[List[List[str]]]:
-    """Rescale by the last ciphertext prime q_last (the leveled-CKKS step after a product): for j < L-1
-        out_c[j] = (c_c[j] - NTT_j(t_c)) * q_last^-1  mod q_j,   t_c = iNTT(c_c[L-1]) + floor(q_last/2)  (mod q_last)
-    with the rounding offset removed again under q_j -- the mod-down of the key-switch with P = q_last.
-    Two phases around one exchange (the coefficient-form last limb goes to every rank through the W buffer):
-    returns [blocks of the owner of q_last, blocks of every rank]."""
-    o, B, L = lo.off, range(lo.B), lo.L
-    qL = lo.moduli[L - 1]
-    half = qL // 2
-    first, second = [], []
-    if (L - 1) in lo.owned_ct:
-        iL = lo.owned_ct.index(L - 1)
-        blk = _setq(qL)
-        for c in range(2):
-            for bi in B:
-                blk += [f"vle v0, abs+{o(lo.s_in(c, iL, bi)):#x}", "vintt v2, v0", "vfqmul.vs v4, v2, 0x1",
-                        f"vfqadd.vs v4, v4, {half:#x}", f"vse v4, abs+{o(lo.rescale_slot(c, bi)):#x}"]
-        first.append(blk)
-    for i, j in enumerate(lo.owned_ct):
-        if j == L - 1:
-            continue
-        q = lo.moduli[j]
-        for c in range(2):
-            for bi in B:                                        # t mod q_j, minus the rounding offset
-                second.append(_setq(q) + _scalar_sum([o(lo.rescale_slot(c, bi))], [1], o(lo.s_s2(c, i, bi)), minus=half % q))
-    for i, j in enumerate(lo.owned_ct):
-        if j == L - 1:
-            continue
-        blk = _setq(lo.moduli[j])
-        for c in range(2):
-            for bi in B:
-                s = o(lo.s_s2(c, i, bi))
-                blk += [f"vle v0, abs+{s:#x}", "vntt v2, v0", f"vse v2, abs+{s:#x}"]
-        second.append(blk)
-    for i, j in enumerate(lo.owned_ct):
-        if j == L - 1:
-            continue
-        q = lo.moduli[j]
-        inv = _inv(qL, q)
-        for c in range(2):
-            for bi in B:
-                second.append(_setq(q) + _scalar_sum([o(lo.s_in(c, i, bi)), o(lo.s_s2(c, i, bi))], [inv, q - inv], o(lo.s_out(c, i, bi))))
-    return [first, second]
-
-
 class HybridKeySwitch:
     """Rotate / multiply with the hybrid key-switch on one rank of ``world``; ``batch`` ciphertexts per call."""
 
@@ -408,25 +170,15 @@ class HybridKeySwitch:
         """``reference_phase1`` (alpha = 1 only): ``rotate`` runs the reference's own phase 1 (iNTT, ``vaut``, NTT) instead of
         the NTT-domain automorphism: identical words except where iNTT(c1) has a zero at a sign-flipped position, which the
         reference lifts as q_d (see ``keyswitch.program_digits``)."""
+        from . import ks as cks
         self.vp = vp
         self.lo = lo = HybridLayout(n, moduli, specials, alpha, world, rank, base_row, batch)
         self.ex = exchange or Exchange()
-        asm = lambda progs: [isa.assemble("\n".join(p)) for p in progs]
-        self._p = {
-            "rot1": asm(_pack(blocks_phase1(lo, "rotate_ref" if reference_phase1 else "rotate"), n)) if lo.Lr else [],
-            "mul1": asm(_pack(blocks_phase1(lo, "multiply"), n)) if lo.Lr else [],
-            "mid": asm(_pack(blocks_modup(lo) + blocks_inner(lo), n)) if lo.Mr else [],
-            "terms": asm(_pack(blocks_moddown_terms(lo), n)) if lo.owned_sp else [],
-            "fin_rot": asm(_pack(blocks_finish(lo, False), n)) if lo.Lr else [],
-            "fin_mul": asm(_pack(blocks_finish(lo, True), n)) if lo.Lr else [],
-            "hoist1": asm(_pack(blocks_phase1(lo, "hoist"), n)) if lo.Lr else [],
-            "modup": asm(_pack(blocks_modup(lo), n)) if lo.Mr else [],
-            "inner_h": asm(_pack(blocks_inner(lo, True), n)) if lo.Mr else [],
-            "fin_h": asm(_pack(blocks_finish(lo, False, True), n)) if lo.Lr else [],
-        }
-        rs = blocks_rescale(lo)
-        self._p["rescale1"] = asm(_pack(rs[0], n)) if rs[0] else []
-        self._p["rescale2"] = asm(_pack(rs[1], n)) if rs[1] else []
+        # a PLAN of the C host (no engine attached): the one generator of the phase programs
+        self._plan = cks.KeySwitch(None, n.bit_length() - 1, moduli, specials, alpha, world, rank, batch, base_row,
+                                   flags=cks.REFERENCE_PHASE1 if reference_phase1 else 0)
+        assert (self._plan.owned_ct, self._plan.owned_all, self._plan.dnum) == (lo.owned_ct, lo.owned_all, lo.dnum)
+        self._p = {name: self._fetch(name) for name in cks.PHASES}
         total = sum(len(w) for ps in self._p.values() for w in ps)
         self._resident = total <= isa.IRAM_DEPTH
         self._pc = {}
@@ -437,6 +189,14 @@ class HybridKeySwitch:
                     vp.load_isram(pc, w)
                     self._pc[(name, idx)] = pc
                     pc += len(w)
+
+    def _fetch(self, name: str):
+        progs = []
+        while True:
+            w = self._plan.program(name, len(progs))
+            if not len(w):
+                return progs
+            progs.append(w)
 
     # -- data placement -------------------------------------------------------------------------
     def load_key(self, key_full: np.ndarray) -> None:
@@ -470,25 +230,43 @@ class HybridKeySwitch:
         return out
 
     # -- the ops ----------------------------------------------------------------------------------
-    def _run(self, name: str, step: int = 0, ksk: int = 0) -> None:
-        for idx, words in enumerate(self._p[name]):
-            if self._resident:
-                pc = self._pc[(name, idx)]
-            else:
-                pc = 0
-                self.vp.load_isram(0, words)
-            rc = self.vp.run(pc, src0=0, src1=0, rslt=0, ksk=ksk, step=step)
-            if rc:
-                raise RuntimeError(f"hybrid key-switch phase {name}[{idx}] failed with status {rc}: "
-                                   f"{getattr(self.vp, 'last_error', '')}")
+    def _run(self, name: str, step: int = 0, ksk: int = 0, scratch=None) -> None:
+        """``scratch`` = (first slot, slots): slots of the layout that only this phase's own instructions read back (the
+        lifted digits between their transform and the inner product, the mod-down's t): declared to the engine as its
+        scratch window for the run (``aloha_vp_set_scratch``), so that it need not write them to memory."""
+        set_scratch = getattr(self.vp, "set_scratch", None) if scratch else None
+        if set_scratch:
+            set_scratch(self.lo.row(scratch[0]), scratch[1] * self.lo.rows)
+        try:
+            for idx, words in enumerate(self._p[name]):
+                if self._resident:
+                    pc = self._pc[(name, idx)]
+                else:
+                    pc = 0
+                    self.vp.load_isram(0, words)
+                rc = self.vp.run(pc, src0=0, src1=0, rslt=0, ksk=ksk, step=step)
+                if rc:
+                    raise RuntimeError(f"hybrid key-switch phase {name}[{idx}] failed with status {rc}: "
+                                       f"{getattr(self.vp, 'last_error', '')}")
+        finally:
+            if set_scratch:
+                set_scratch(0, 0)
+
+    @property
+    def _sd_slots(self):
+        return (self.lo.sd, self.lo.Mr * self.lo.dnum * self.lo.B)
+
+    @property
+    def _s2_slots(self):
+        return (self.lo.s2, 2 * self.lo.Lr * self.lo.B)
 
     def _switch(self, finish: str) -> None:
         lo = self.lo
         self.ex.all_gather(self.vp, lo.row(lo.y), lo.Yr * lo.B * lo.n, lo.world, lo.rank)
-        self._run("mid")
+        self._run("mid", scratch=self._sd_slots)
         self._run("terms")
         self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.B * lo.n, lo.world, lo.rank)
-        self._run(finish)
+        self._run(finish, scratch=self._s2_slots)
 
     def rotate(self, k: int) -> None:
         self._run("rot1", step=k)
@@ -530,16 +308,15 @@ class HybridKeySwitch:
         self._run("inner_h", ksk=index * self.key_rows)
         self._run("terms")
         self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.B * lo.n, lo.world, lo.rank)
-        self._run("fin_h", step=k)
+        self._run("fin_h", step=k, scratch=self._s2_slots)
 
     def hoist_one(self) -> None:
         """``hoist()`` for the ciphertext in slot 0 only: the other ``batch`` slots then serve as ROTATION slots of
         ``rotate_hoisted_many``."""
         lo = self.lo
         if "hoist1_1" not in self._p:
-            asm = lambda progs: [isa.assemble("\n".join(p)) for p in progs]
-            self._p["hoist1_1"] = asm(_pack(blocks_phase1(lo, "hoist", range(1)), lo.n)) if lo.Lr else []
-            self._p["modup_1"] = asm(_pack(blocks_modup(lo, range(1)), lo.n)) if lo.Mr else []
+            self._plan.hoist(first_slot_only=True)                # (a plan: generates the two programs, runs nothing)
+            self._p["hoist1_1"], self._p["modup_1"] = self._fetch("hoist1_1"), self._fetch("modup_1")
             self._resident = False
         self._run("hoist1_1")
         self.ex.all_gather(self.vp, lo.row(lo.y), lo.Yr * lo.B * lo.n, lo.world, lo.rank)
@@ -556,16 +333,15 @@ class HybridKeySwitch:
         assert 0 < len(steps) <= lo.B and len(regions) == len(steps)
         key = ("many", tuple(steps), tuple(regions))
         if key not in self._p:
-            asm = lambda progs: [isa.assemble("\n".join(p)) for p in progs]
-            R = range(len(steps))
-            self._p[key] = asm(_pack(blocks_inner(lo, True, regions), lo.n)) if lo.Mr else []
-            self._p[key + ("terms",)] = asm(_pack(blocks_moddown_terms(lo, R), lo.n)) if lo.owned_sp else []
-            self._p[key + ("fin",)] = asm(_pack(blocks_finish(lo, False, True, steps), lo.n)) if lo.Lr else []
+            self._plan.rotate_hoisted_many(steps, regions)        # (a plan: generates the three programs, runs nothing)
+            self._p[key] = self._fetch("many")
+            self._p[key + ("terms",)] = self._fetch("many_terms")
+            self._p[key + ("fin",)] = self._fetch("many_fin")
             self._resident = False
         self._run(key)
         self._run(key + ("terms",))
         self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.B * lo.n, lo.world, lo.rank)
-        self._run(key + ("fin",))
+        self._run(key + ("fin",), scratch=self._s2_slots)
 
     def rescale(self) -> None:
         """CT_IN (L limbs) -> OUT (limbs 0 .. L-2 valid): divide by the last ciphertext prime, rounding.
@@ -573,4 +349,4 @@ class HybridKeySwitch:
         lo = self.lo
         self._run("rescale1")
         self.ex.all_gather(self.vp, lo.row(lo.w), lo.Wr * lo.B * lo.n, lo.world, lo.rank)
-        self._run("rescale2")
+        self._run("rescale2", scratch=self._s2_slots)

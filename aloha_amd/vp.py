@@ -57,7 +57,7 @@ class _Config(C.Structure):
 class _Stats(C.Structure):
     _fields_ = [("instructions", C.c_uint64), ("kernel_launches", C.c_uint64), ("twiddle_builds", C.c_uint64),
                 ("fused_launches", C.c_uint64), ("graph_launches", C.c_uint64),
-                ("twiddle_generations", C.c_uint64)]
+                ("twiddle_generations", C.c_uint64), ("ks_fused_launches", C.c_uint64)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -246,7 +246,8 @@ class VP:
         self._chk(self._L.aloha_vp_get_stats(self._h, C.byref(s)))
         return {"instructions": int(s.instructions), "kernel_launches": int(s.kernel_launches),
                 "twiddle_builds": int(s.twiddle_builds), "fused_launches": int(s.fused_launches),
-                "graph_launches": int(s.graph_launches), "twiddle_generations": int(s.twiddle_generations)}
+                "graph_launches": int(s.graph_launches), "twiddle_generations": int(s.twiddle_generations),
+                "ks_fused_launches": int(s.ks_fused_launches)}
 
     def peek_vreg(self, reg: int, n: int) -> np.ndarray:
         out = np.empty(n, dtype=np.uint64)

@@ -244,9 +244,10 @@ typedef struct {
   uint64_t instructions;    /* instructions retired since create                             */
   uint64_t kernel_launches; /* HIP kernel launches issued                                    */
   uint64_t twiddle_builds;  /* (q, N) twiddle tables generated                               */
-  uint64_t fused_launches;  /* of kernel_launches: N = 2^16 forward transforms run as ONE launch (ABI 2) */
+  uint64_t fused_launches;  /* variant builds: N = 2^16 forward transforms run as ONE launch (ABI 2)   */
   uint64_t graph_launches;  /* aloha_vp_run calls served by one hipGraphLaunch of a recorded run (ABI 2) */
   uint64_t twiddle_generations; /* times the bounded twiddle cache was emptied to make room (ABI 2)     */
+  uint64_t ks_fused_launches;   /* of kernel_launches: key-switch kernels that absorbed neighbouring sums (ABI 3)  */
 } aloha_vp_stats;
 aloha_status aloha_vp_get_stats(const aloha_vp *vp, aloha_vp_stats *out);
 /* copy a vector register to the host (debug; not architecturally visible in the reference) */

@@ -18,6 +18,8 @@ aloha_status aloha_vp_sync(aloha_vp *) { abort(); }
 void *aloha_vp_device_ptr(aloha_vp *, int, uint64_t) { abort(); }
 void *aloha_vp_stream(aloha_vp *) { abort(); }
 int aloha_vp_device(const aloha_vp *) { abort(); }
+aloha_status aloha_vp_get_config(const aloha_vp *, aloha_vp_config *) { abort(); }
+aloha_status aloha_vp_set_scratch(aloha_vp *, uint64_t, uint64_t) { abort(); }
 const char *aloha_vp_last_error(const aloha_vp *) { return ""; }
 // the two HIP runtime calls of aloha_ks_comm_init (never reached by a plan): no libamdhip64 in a sanitizer build
 hipError_t hipGetDevice(int *) { abort(); }

@@ -1,15 +1,20 @@
-"""GPU parity of the fused single-launch forward transform at N = 2^16 (ntt_tile.hip: ntt_fused_fwd_kernel --
+"""(Run by tests/test_experiments.py in a process of its own, with ALOHA_VP_LIB = the experiments variant of the library.)
+GPU parity of the fused single-launch forward transform at N = 2^16 (csrc/experiments/ntt_tile_knobs.hip: ntt_fused_fwd_kernel --
 column and row tiles in ONE persistent launch, the intermediate handed over through the Infinity Cache) against the
 oracle and against the two-launch form of the same engine.  Bit-exact.  Reference: vntt, one pass over the register
 file (src/vp/ntt/ntt_fsm.sv:49-81, modalu.sv:160-165); results per SURVEY A.2.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
 
-import oracle
-from aloha_amd import vp as avp
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/ (util, conftest)
+
+import oracle  # noqa: E402
+from aloha_amd import isa  # noqa: E402
+from aloha_amd import vp as avp  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -143,3 +148,29 @@ def test_small_or_ragged_batches_keep_the_two_launch_form():
             got = vp.read(SPM, 0, len(mods) * N).reshape(len(mods), N)
             for i, q in enumerate(mods):
                 assert np.array_equal(got[i], oracle.ntt(data[i], q))
+
+
+def test_recorded_runs_replayed_as_hipgraphs(monkeypatch):
+    """ALOHA_RUN_GRAPH=1 (variant builds): a recorded run becomes a hipGraph on its second replay; results stay those of
+    the oracle's ISA machine."""
+    monkeypatch.setenv("ALOHA_RUN_GRAPH", "1")
+    logn, n = 12, 1 << 12
+    rows = n // 128
+    q = oracle.nth_prime(13, 0)
+    prog = [f"vsetvl {64 * n:#x}", f"vsetq {q:#x}"]
+    for i in range(4):
+        prog += [f"vle v0, src0+{i * 8 * n:#x}", "vntt v2, v0", f"vse v2, rslt+{i * 8 * n:#x}"]
+    prog += [f"vle v0, rslt+0x0", f"vle v1, rslt+{8 * n:#x}", "vfqmul.vv v2, v0, v1", f"vse v2, rslt+{4 * 8 * n:#x}", "break"]
+    words = isa.assemble("\n".join(prog))
+    rng = np.random.default_rng(3)
+    with avp.VP(spm_rows=16 * rows, ksk_rows=1, max_log_n=logn) as vp:
+        o = oracle.OracleVP(spm_rows=16 * rows, ksk_rows=1)
+        vp.load_isram(0, words); o.load_isram(0, words)
+        for rep in range(4):
+            data = rng.integers(0, q, 4 * n, dtype=np.uint64)
+            for e in (vp, o):
+                e.write(SPM, 0, data)
+                assert e.run(0, src0=0, rslt=8 * rows) == 0
+                e.sync()
+            assert np.array_equal(vp.read(SPM, 8 * rows, 5 * n), o.read(SPM, 8 * rows, 5 * n)), rep
+        assert vp.stats()["graph_launches"] >= 1

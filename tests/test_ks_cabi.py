@@ -1,32 +1,25 @@
-"""The C host's key-switch (aloha_ks_*, csrc/keyswitch_host.cpp) against the Python generator that drives the oracle's
-ISA machine (aloha_amd/hybrid.py): on the CPU the two program generators must agree WORD FOR WORD for every phase, rank
-and layout; on the GPU the C host's results must equal the oracle machine's, with and without a (one-rank) RCCL
-communicator.  Reference step: the rotate / key-switch micro-program keyswitch.mem:1-122 and its driver run_rotate
+"""The C host's key-switch (aloha_ks_*, csrc/keyswitch_host.cpp).  Its program generator is the only one: the Python driver
+of aloha_amd/hybrid.py -- which runs the oracle's ISA machine in the parity tests -- fetches the same words through
+aloha_ks_program.  On the CPU: the Python slot-layout mirror agrees with the C host, bad configurations are refused; on
+the GPU: the C host's results equal the oracle machine's, with and without a (one-rank) RCCL communicator.  Reference step: the rotate / key-switch micro-program keyswitch.mem:1-122 and its driver run_rotate
 (top_noaxilite_tb.sv:522-532)."""
 import numpy as np
 import pytest
 
 import oracle
-from aloha_amd import hybrid, isa, ks
+from aloha_amd import hybrid, isa, keyswitch, ks
 from aloha_amd import vp as avp
 from util import N, P, Q0, Q1, load, manifest
+
+
+def _mnemonics(words):
+    form = {0: ".vv", 1: ".vs", 2: ".sv"}
+    return [i.name + (form[i.funct3] if i.name in ("vfqmul", "vfqadd", "vfqsub") else "") for i in isa.insts_of(words)]
 
 
 def _setup(n, L, K):
     logn = n.bit_length() - 1
     return [oracle.nth_prime(logn, i) for i in range(L)], [oracle.nth_prime(logn, L + k) for k in range(K)]
-
-
-PY_PHASE = {"rot1": lambda lo: hybrid.blocks_phase1(lo, "rotate"), "mul1": lambda lo: hybrid.blocks_phase1(lo, "multiply"),
-            "mid": lambda lo: hybrid.blocks_modup(lo) + hybrid.blocks_inner(lo), "terms": hybrid.blocks_moddown_terms,
-            "fin_rot": lambda lo: hybrid.blocks_finish(lo, False), "fin_mul": lambda lo: hybrid.blocks_finish(lo, True)}
-PY_PHASE.update({"hoist1": lambda lo: hybrid.blocks_phase1(lo, "hoist"), "modup": hybrid.blocks_modup,
-                 "inner_h": lambda lo: hybrid.blocks_inner(lo, True), "fin_h": lambda lo: hybrid.blocks_finish(lo, False, True),
-                 "rescale1": lambda lo: hybrid.blocks_rescale(lo)[0], "rescale2": lambda lo: hybrid.blocks_rescale(lo)[1]})
-PY_COND = {"rot1": lambda lo: lo.Lr, "mul1": lambda lo: lo.Lr, "mid": lambda lo: lo.Mr, "terms": lambda lo: lo.owned_sp,
-           "fin_rot": lambda lo: lo.Lr, "fin_mul": lambda lo: lo.Lr, "hoist1": lambda lo: lo.Lr, "modup": lambda lo: lo.Mr,
-           "inner_h": lambda lo: lo.Mr, "fin_h": lambda lo: lo.Lr, "rescale1": lambda lo: hybrid.blocks_rescale(lo)[0],
-           "rescale2": lambda lo: hybrid.blocks_rescale(lo)[1]}
 
 
 @pytest.mark.parametrize("logn,L,K,alpha,world,batch", [
@@ -36,7 +29,10 @@ PY_COND = {"rot1": lambda lo: lo.Lr, "mul1": lambda lo: lo.Lr, "mid": lambda lo:
     (16, 24, 4, 4, 8, 1),      # BASELINE config 4 on 8 ranks
     (16, 32, 4, 4, 8, 2), (16, 24, 1, 1, 1, 1),   # config 5; the reference's decomposition at L = 24 (programs split over the ROM)
 ])
-def test_c_host_programs_equal_the_python_generator_word_for_word(logn, L, K, alpha, world, batch):
+def test_c_host_plan_and_the_python_layout_mirror_agree(logn, L, K, alpha, world, batch):
+    """There is ONE generator of the phase programs, the C host's (aloha_ks_program); hybrid.py fetches its words and keeps
+    only the slot layout for placing data.  That mirror must agree with the C host on everything a caller can observe:
+    ownership, digit count, rows needed, the two gather buffers -- and the driver must hold exactly the plan's programs."""
     n = 1 << logn
     mods, specials = _setup(n, L, K)
     for rank in range(world):
@@ -44,25 +40,37 @@ def test_c_host_programs_equal_the_python_generator_word_for_word(logn, L, K, al
         with ks.KeySwitch(None, logn, mods, specials, alpha, world, rank, batch, base_row=7) as k:
             assert (k.owned_ct, k.owned_all, k.dnum) == (lo.owned_ct, lo.owned_all, lo.dnum)
             assert ks.rows_needed(logn, mods, specials, alpha, world, rank, batch, 7) == (lo.spm_rows_needed, max(1, lo.ksk_limbs * lo.rows))
+            assert k.gather_buffer(0) == (lo.row(lo.y), lo.Yr * lo.B * n) and k.gather_buffer(1) == (lo.row(lo.w), lo.Wr * lo.B * n)
+            hs = hybrid.HybridKeySwitch(_RomOnly(), n, mods, specials, alpha, world=world, rank=rank, batch=batch, base_row=7)
             for phase in ks.PHASES:
-                progs = [isa.assemble("\n".join(p)) for p in hybrid._pack(PY_PHASE[phase](lo), n)] if PY_COND[phase](lo) else []
+                progs = hs._p[phase]
                 for idx, words in enumerate(progs):
-                    assert np.array_equal(k.program(phase, idx), words), f"rank {rank} phase {phase}[{idx}]"
+                    assert np.array_equal(k.program(phase, idx), words) and len(words) <= isa.IRAM_DEPTH
                 assert k.program(phase, len(progs)).shape == (0, 3)
+            # "mid" is cut by modulus: every program holds whole chains (sums, transforms, inner products of its moduli)
+            for words in hs._p["mid"]:
+                names = _mnemonics(words)
+                assert "vntt" in names and "vfqmul.vv" in names and ("vfqmul.vs" in names or lo.dnum == 1)
+                first_ntt, last_ntt = names.index("vntt"), len(names) - 1 - names[::-1].index("vntt")
+                assert "vfqmul.vv" not in names[:last_ntt] and "vfqmul.vs" not in names[first_ntt:]
             # programs generated on demand: the decomposition of slot 0 only, and `batch` rotations in one pass
-            k.hoist(first_slot_only=True)
             steps = [pow(3, b + 2, 2 * n) for b in range(batch)]
-            regions = list(range(batch))[::-1]
-            k.rotate_hoisted_many(steps, regions)
-            R = range(batch)
-            dyn = {"hoist1_1": (lo.Lr, hybrid.blocks_phase1(lo, "hoist", range(1))), "modup_1": (lo.Mr, hybrid.blocks_modup(lo, range(1))),
-                   "many": (lo.Mr, hybrid.blocks_inner(lo, True, regions)), "many_terms": (lo.owned_sp, hybrid.blocks_moddown_terms(lo, R)),
-                   "many_fin": (lo.Lr, hybrid.blocks_finish(lo, False, True, steps))}
-            for phase, (cond, blocks) in dyn.items():
-                progs = [isa.assemble("\n".join(p)) for p in hybrid._pack(blocks, n)] if cond else []
-                for idx, words in enumerate(progs):
-                    assert np.array_equal(k.program(phase, idx), words), f"rank {rank} phase {phase}[{idx}]"
-                assert k.program(phase, len(progs)).shape == (0, 3)
+            hs.vp.runs = 0
+            hs.ex = keyswitch.Exchange(stub=True)
+            hs.hoist_one(); hs.rotate_hoisted_many(steps, list(range(batch))[::-1])
+            assert hs.vp.runs > 0
+
+
+class _RomOnly:
+    """Just enough of a VP for program generation."""
+    runs = 0
+
+    def load_isram(self, pc, words):
+        assert pc + len(words) <= 4096
+
+    def run(self, *a, **kw):
+        self.runs += 1
+        return 0
 
 
 def test_c_host_rejects_bad_configs():
@@ -208,9 +216,8 @@ def test_reference_phase1_of_the_generators_is_the_reference_algorithm_at_the_ze
     assert np.array_equal(outs[True], exp)
     assert not np.array_equal(outs[False], exp)                  # the corner is real: the two phase-1 forms differ here
     with ks.KeySwitch(None, 13, [Q0, Q1], [P], 1, flags=ks.REFERENCE_PHASE1) as plan:
-        lo = hybrid.HybridLayout(N, [Q0, Q1], [P], 1)
-        words = isa.assemble("\n".join(hybrid._pack(hybrid.blocks_phase1(lo, "rotate_ref"), N)[0]))
-        assert np.array_equal(plan.program("rot1", 0), words)
+        names = _mnemonics(plan.program("rot1", 0))
+        assert names.count("vaut") == 4 and names.count("vintt") == 4 and "vautn" not in names   # keyswitch.mem:4-7,:24-27 per limb
     with pytest.raises(avp.AlohaError):
         ks.KeySwitch(None, 13, [Q0, Q1, oracle.nth_prime(13, 5)], [P], 2, flags=ks.REFERENCE_PHASE1)   # alpha = 1 only
 
@@ -292,3 +299,27 @@ def test_c_host_sharded_over_ranks_with_the_exchanges_carried_by_the_host(tmp_pa
             assert np.array_equal(out[:, i], exp[:, j]), f"rank {r} limb {j}"
             seen.add(int(j))
     assert seen == set(range(L))
+
+
+def test_c_host_rejects_bad_moduli():
+    """A zero, even, composite, out-of-range, repeated or rootless modulus is refused by aloha_ks_create /
+    aloha_ks_rows_needed with a status (a zero modulus used to end the process with SIGFPE in the layout's `1 % m`)."""
+    good = [oracle.nth_prime(13, i) for i in range(3)]
+    sp = [oracle.nth_prime(13, 3)]
+    for mods, specials, status in [
+            ([good[0], 0], sp, avp.ERR_MODULUS), ([good[0], good[1] + 1], sp, avp.ERR_MODULUS),       # zero; even
+            ([good[0], good[0]], sp, avp.ERR_MODULUS), ([good[0], good[1]], [good[1]], avp.ERR_MODULUS),   # repeated (also across the two lists)
+            ([good[0], (1 << 61) + 1], sp, avp.ERR_MODULUS), ([good[0], good[1] - 2], sp, avp.ERR_MODULUS),  # > 60 bits; composite or not 1 mod 2N
+            ([good[0], P], sp, None)]:                                                                 # P = 1 mod 2^14 only: fine at N = 2^13 ...
+        if status is None:
+            with ks.KeySwitch(None, 13, mods, specials, 1):
+                pass
+            with pytest.raises(avp.AlohaError) as e:
+                ks.KeySwitch(None, 14, mods, specials, 1)                                              # ... no 2N-th root at N = 2^14
+            assert e.value.status == avp.ERR_ROOT
+            continue
+        with pytest.raises(avp.AlohaError) as e:
+            ks.KeySwitch(None, 13, mods, specials, 1)
+        assert e.value.status == status, (mods, e.value.status)
+        with pytest.raises(avp.AlohaError):
+            ks.rows_needed(13, mods, specials, 1)
