@@ -188,16 +188,22 @@ __device__ __forceinline__ void products_chunk(const u64 (&v)[16], int m, cgptr_
   }
 }
 
-template <int R>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 2 ? 4 : 3, R == 2 ? 4 : 3))) void ntt_rowdot_kernel(
+// S waves per workgroup share the digits of one (group, R rows): each takes a contiguous share of the blocks, wave 0 adds the
+// accumulators of the others (through LDS) and stores.  A wave's chain of tiles is serial -- load, transform, load the
+// key, multiply -- and a key-switch has few groups, so at S = 1 the kernel's time was one wave's latency (the same ~100 us for
+// 18 groups as for 28); S = 2 halves the chain and doubles the waves.
+template <int R, int S>
+__global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(R == 2 ? 4 : 3, R == 2 ? 4 : 3))) void ntt_rowdot_kernel(
     const RowDotGroup *__restrict__ groups, const PrimeDev *__restrict__ primes) {
   constexpr int DSH = R == 4 ? 2 : 1, DPT = 4 / R;               // remainder tiles: DPT digits x R rows
   constexpr int PRE = R == 2 ? 0 : 3;                            // second-step twiddles issued early (registers against latency)
-  constexpr uint32_t WPG = 256 / R;                              // waves per group
-  __shared__ u64 lds[4 * RP];
+  constexpr uint32_t WPG = 256 / R;                              // workgroups per group
+  __shared__ u64 lds_all[S * 4 * RP];
+  const uint32_t wv = S > 1 ? uni(threadIdx.x >> 6) : 0;
+  u64 *lds = lds_all + wv * 4 * RP;
   const RowDotGroup *g = &groups[blockIdx.x / WPG];
   const uint32_t r0 = (blockIdx.x % WPG) * R;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const PrimeDev *pr = &primes[g->prime];
   const u64 q = pr->m.q, nq = pr->m.nq, mu = pr->m.mu;
   const u32 kc = (u32)pr->m.kc;
@@ -219,8 +225,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 2 ? 4 :
   const uint32_t rowA = r0 + (L.lwA & (R - 1)), rowB = r0 + (L.lwB & (R - 1));
   const uint32_t offP = (rowA << 8) + L.plA;
   ctw_t blkA = gtw + (size_t)rowA * TW_BLK, blkB = gtw + (size_t)rowB * TW_BLK;
-  uint32_t b = (blockIdx.x >> 3) % nblocks;                      // (blocks 8 apart share an XCD)
-  for (uint32_t bi = 0; bi < nblocks; bi++, b = b + 1 == nblocks ? 0 : b + 1) {
+  // this wave's share [b_lo, b_hi) of the blocks, by cost (a tile with a transform 2, a plain one 1): the block whose
+  // midpoint falls into the wave's S-th of the total
+  uint32_t b_lo = 0, b_hi = nblocks;
+  if (S > 1) {
+    const uint32_t total = 2 * (2 * R * nquad + 2 * ntr + npl);
+    uint32_t pre = 0;
+    b_lo = b_hi = nblocks;
+    for (uint32_t bb = 0; bb < nblocks; bb++) {
+      const uint32_t cost = 2 * (bb < nquad ? 2 * R : bb < nquad + ntr ? 2 : 1);
+      const uint32_t owner = (pre + cost / 2) * S / total;
+      if (owner == wv && b_lo == nblocks) b_lo = bb;
+      if (owner > wv && b_hi == nblocks) b_hi = bb;
+      pre += cost;
+    }
+    if (b_lo == nblocks) b_lo = b_hi = 0;                        // (no share: fewer blocks than waves)
+  }
+  const uint32_t nmine = b_hi - b_lo;
+  uint32_t b = nmine ? b_lo + (blockIdx.x >> 3) % nmine : 0;    // (workgroups 8 apart share an XCD)
+  for (uint32_t bi = 0; bi < nmine; bi++, b = b + 1 == b_hi ? b_lo : b + 1) {
     if (b < nquad) {
       // -- four digits, row by row: 4 lines = row r0 + i of digits 4 b + lw ------------------------------------------------
       const uint32_t dA = 4 * b + L.lwA;
@@ -293,6 +316,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 2 ? 4 :
     }
   }
 
+  // -- the other waves' shares ------------------------------------------------------------------------------------------
+  if (S > 1) {
+    __syncthreads();                                             // every wave is done with its transpose region
+    if (wv) {
+#pragma unroll
+      for (int i = 0; i < R; i++)
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int c = 0; c < 2; c++) lds[((i * 4 + m) * 2 + c) * 64 + lane] = A[i][m][c];
+    }
+    __syncthreads();
+    if (wv) return;
+#pragma unroll
+    for (int w = 1; w < S; w++)
+#pragma unroll
+      for (int i = 0; i < R; i++)
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int c = 0; c < 2; c++) A[i][m][c] = csub_u(A[i][m][c] + lds_all[w * 4 * RP + ((i * 4 + m) * 2 + c) * 64 + lane], eightq);
+  }
+
   // -- canonical results, 128-byte segments ----------------------------------------------------------------------------
   const uint32_t kbase = 2 * (L.lwA & 1) + (L.lwA >> 1);
 #pragma unroll
@@ -334,9 +380,12 @@ hipError_t ntt_fwd16_rowdot(hipStream_t st, const RowDotGroup *d_groups, uint32_
   // few groups (a key-switch of one ciphertext: 28 at L = 24): two rows per wave, twice the waves at 4 per SIMD; batches
   // of ciphertexts fill the chip with four rows per wave and no idle lines.  (ALOHA_ROWDOT_ROWS: A/B timing switch)
   static const int forced = getenv("ALOHA_ROWDOT_ROWS") ? atoi(getenv("ALOHA_ROWDOT_ROWS")) : 0;
+  static const int forced_split = getenv("ALOHA_ROWDOT_SPLIT") ? atoi(getenv("ALOHA_ROWDOT_SPLIT")) : 0;
   const bool two = forced ? forced == 2 : ngroups < 96;
-  if (two) hipLaunchKernelGGL(ntt_rowdot_kernel<2>, dim3(ngroups * 128), dim3(64), 0, st, d_groups, d_primes);
-  else hipLaunchKernelGGL(ntt_rowdot_kernel<4>, dim3(ngroups * 64), dim3(64), 0, st, d_groups, d_primes);
+  const bool split = forced_split ? forced_split == 2 : ngroups < 48;
+  if (two && split) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 2>), dim3(ngroups * 128), dim3(128), 0, st, d_groups, d_primes);
+  else if (two) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 1>), dim3(ngroups * 128), dim3(64), 0, st, d_groups, d_primes);
+  else hipLaunchKernelGGL((ntt_rowdot_kernel<4, 1>), dim3(ngroups * 64), dim3(64), 0, st, d_groups, d_primes);
   if (launches) ++*launches;
   return hipGetLastError();
 }

@@ -165,6 +165,143 @@ def cpu_baseline(seconds: float = 8.0, check=None) -> dict:
                                       "cycles_per_ntt_n8192": 850, "ntt_per_s_n8192": 1e8 / 850}}
 
 
+# Design ceilings of the headline transform, each MEASURED on this chip (frac of the 16*N HBM roofline):
+CEILINGS = {
+    "two_pass_memory": {"frac": 0.375, "source": "profiles/r01_c_ubench_mem.txt",
+                        "what": "read+write streams with the two passes' access patterns (6.05-6.1 TB/s each): 357 us per 1024 limbs -- a 512 KiB limb "
+                                "does not fit a CU's 160 KiB LDS, so the transform is two HBM round trips whatever the arithmetic costs"},
+    "single_round_trip_skeleton": {"frac": 0.447, "source": "profiles/r02_c_ubench_icfuse.txt",
+                                   "what": "memory skeleton of ONE launch handing the intermediate over through the Infinity Cache: 1200 us per 4096 "
+                                           "limbs; as real kernels 1.88-2.13 ms (variant build, csrc/experiments)"},
+}
+
+
+def configs_leg(device: int, budget_s: float = 55.0) -> dict:
+    """BASELINE.json configs 2-5 on this GPU, bounded (the default bench run stays within minutes): per config the time, the
+    ALGORITHMIC bytes by SURVEY.md 8d's formulas (aloha_amd/accounting.py; the itemised sum is printed), the fraction of the
+    8 TB/s roofline, `verified` (every output word against the CPU oracle's ISA machine, in the untimed part) and the CPU
+    port's time for the same operation (that verification run, one thread).  Config 1 is the reference's CPU-runnable case
+    (parity tests only).  Key-switch = the hybrid form the product recommends (alpha = K = 4)."""
+    import oracle
+    from aloha_amd import accounting as acc
+    from aloha_amd import hybrid, isa, programs
+    from aloha_amd import vp as avp
+    t_start = time.perf_counter()
+    out = {"note": "one GPU, inputs resident in HBM; frac = algorithmic bytes / time / 8 TB/s; cpu_port_ms = the oracle (kind: port), one thread, same operation"}
+    SPM, KSK = 0, 1
+
+    def timeit(fn, sync, reps):
+        fn(); sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / reps
+
+    # -- config 2: one forward NTT at N = 2^12 (latency), and batched -----------------------------------------------------
+    logn, n = 12, 1 << 12
+    q = avp.nth_prime(logn, 0)
+    rng = np.random.default_rng(2)
+    with avp.VP(spm_rows=4096 * n // 128, ksk_rows=1, max_log_n=12, device=device) as vp:
+        a = rng.integers(0, q, n, dtype=np.uint64)
+        vp.write(SPM, 0, a)
+        vp.ntt_rows(SPM, n // 128, 0, logn, [q])
+        t0 = time.perf_counter(); exp = oracle.ntt(a, q); cpu_ms = (time.perf_counter() - t0) * 1e3
+        ok = bool(np.array_equal(vp.read(SPM, n // 128, n), exp))
+        t1 = timeit(lambda: (vp.ntt_rows(SPM, 0, 0, logn, [q]), vp.sync()), vp.sync, 200)
+        B = 4096
+        tb = timeit(lambda: vp.ntt_rows(SPM, 0, 0, logn, [q] * B), vp.sync, 50)
+        out["config2_ntt_n4096"] = {"single_call_us": t1 * 1e6, "batched_ntt_per_s": B / tb, "algorithmic_bytes": acc.ntt_bytes(n, B),
+                                    "batched_GBps": acc.ntt_bytes(n, B) / tb / 1e9, "frac": acc.ntt_bytes(n, B) / tb / 1e9 / HBM_PEAK_GBS,
+                                    "verified": ok, "cpu_port_ms": cpu_ms}
+    # -- config 3: 8-limb polynomial product at N = 2^14 ------------------------------------------------------------------
+    logn, n, L = 14, 1 << 14, 8
+    rows = n // 128
+    mods = [avp.nth_prime(logn, i) for i in range(L)]
+    rng = np.random.default_rng(3)
+    a = np.stack([rng.integers(0, m, n, dtype=np.uint64) for m in mods])
+    b = np.stack([rng.integers(0, m, n, dtype=np.uint64) for m in mods])
+    words = programs.assemble(programs.poly_mul_batched(n, mods, scratch_row=3 * L * rows))
+    with avp.VP(spm_rows=4 * L * rows, ksk_rows=1, max_log_n=14, device=device) as vp:
+        o = oracle.OracleVP(spm_rows=4 * L * rows, ksk_rows=1)
+        for e in (vp, o):
+            e.write(SPM, 0, a.reshape(-1)); e.write(SPM, L * rows, b.reshape(-1)); e.load_isram(0, words)
+        run = lambda: vp.run(0, src0=0, src1=L * rows, rslt=2 * L * rows)
+        assert run() == 0
+        t0 = time.perf_counter(); assert o.run(0, src0=0, src1=L * rows, rslt=2 * L * rows) == 0; cpu_ms = (time.perf_counter() - t0) * 1e3
+        ok = bool(np.array_equal(vp.read(SPM, 2 * L * rows, L * n), o.read(SPM, 2 * L * rows, L * n)))
+        l0 = vp.stats()["kernel_launches"]
+        t = timeit(run, vp.sync, 100)
+        by = acc.polymul_bytes(n, L)
+        out["config3_polymul_n16384_8limbs"] = {"us": t * 1e6, "launches": (vp.stats()["kernel_launches"] - l0) / 101, "algorithmic_bytes": by,
+                                                "fused_min_GBps": by["fused_minimum"] / t / 1e9, "frac": by["fused_minimum"] / t / 1e9 / HBM_PEAK_GBS,
+                                                "verified": ok, "cpu_port_ms": cpu_ms}
+        o.close()
+
+    # -- configs 4 / 5: HMult + relinearisation at L = 24, rotate + key-switch at L = 32 (N = 2^16, hybrid alpha = K = 4) -------
+    def keyswitch(L, op):
+        logn, n, alpha = 16, 1 << 16, 4
+        mods = [avp.nth_prime(logn, i) for i in range(L)]
+        specials = [avp.nth_prime(logn, L + k) for k in range(alpha)]
+        lo = hybrid.HybridLayout(n, mods, specials, alpha)
+        sizes = dict(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows)
+        k = pow(3, 5, 2 * n)
+        with avp.VP(max_log_n=16, device=device, **sizes) as vp:
+            hs = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha)
+            # synthetic key and ciphertexts straight into HBM (SURVEY 8d's splitmix64 rule), copied out once for the oracle
+            vp.fill_synthetic(KSK, 0, logn, [m for m in lo.mods_all for _ in range(lo.dnum * 2)], seed_base=0xA10A + 7000)
+            for base, seed in ((lo.ct_in, 1), (lo.ct_b, 2)):
+                vp.fill_synthetic(SPM, lo.row(base), logn, [mods[j] for _ in range(2) for j in range(L)], seed_base=0xA10A + 100000 * seed)
+            res = {}
+            verify = time.perf_counter() - t_start < budget_s - (12.0 if L > 24 else 8.0)
+            if verify:
+                o = oracle.OracleVP(**sizes)
+                ho = hybrid.HybridKeySwitch(o, n, mods, specials, alpha)
+                o.write(KSK, 0, vp.read(KSK, 0, lo.ksk_limbs * n))
+                for base in (lo.ct_in, lo.ct_b):
+                    o.write(SPM, lo.row(base), vp.read(SPM, lo.row(base), 2 * L * n))
+                t0 = time.perf_counter()
+                ho.multiply() if op == "multiply" else ho.rotate(k)
+                res["cpu_port_ms"] = (time.perf_counter() - t0) * 1e3
+            run = (lambda: hs.multiply()) if op == "multiply" else (lambda: hs.rotate(k))
+            run(); vp.sync()
+            if verify:
+                res["verified"] = bool(np.array_equal(hs.read_out(), ho.read_out()))
+                o.close()
+            else:
+                res["verified"] = None
+            l0 = vp.stats()["kernel_launches"]
+            t = timeit(run, vp.sync, 10)
+            by = acc.keyswitch_bytes(n, L, alpha, lo.dnum, op)
+            res.update({"ms": t * 1e3, "launches": (vp.stats()["kernel_launches"] - l0) / 11, "L": L, "K": alpha, "alpha": alpha, "dnum": lo.dnum,
+                        "algorithmic_bytes": by, "GBps": by["survey_total"] / t / 1e9, "frac": by["survey_total"] / t / 1e9 / HBM_PEAK_GBS,
+                        "frac_lean": by["lean_total"] / t / 1e9 / HBM_PEAK_GBS})
+            return res
+
+    out["config4_hmult_relin_n65536_L24"] = keyswitch(24, "multiply")
+    out["config5_rotate_keyswitch_n65536_L32"] = keyswitch(32, "rotate")
+    # -- config 5: the automorphism alone (vaut, 64 limbs) ---------------------------------------------------------------------
+    logn, n, B = 16, 1 << 16, 64
+    q = avp.nth_prime(logn, 0)
+    rows = n // 128
+    lines = [f"vsetvl {64 * n:#x}", f"vsetq {q:#x}"]
+    for i in range(B):
+        lines += [f"vle v0, src0+{i * 8 * n:#x}", "vaut v2, v0, 0x0", f"vse v2, rslt+{i * 8 * n:#x}"]
+    with avp.VP(spm_rows=2 * B * rows, ksk_rows=1, max_log_n=16, device=device) as vp:
+        vp.fill_synthetic(SPM, 0, logn, [q] * B, seed_base=0xA10A + 500000)
+        vp.load_isram(0, isa.assemble("\n".join(lines + ["break"])))
+        kk = pow(3, 7, 2 * n)
+        run = lambda: vp.run(0, src0=0, rslt=B * rows, step=kk)
+        assert run() == 0
+        t0 = time.perf_counter(); exp = oracle.vaut(vp.read(SPM, 0, n), q, kk); cpu_ms = (time.perf_counter() - t0) * 1e3
+        ok = bool(np.array_equal(vp.read(SPM, B * rows, n), exp))
+        t = timeit(run, vp.sync, 20)
+        out["config5_automorphism_64limbs"] = {"us_per_limb": t / B * 1e6, "algorithmic_bytes": 16 * n * B, "GBps": 16 * n * B / t / 1e9,
+                                               "frac": 16 * n * B / t / 1e9 / HBM_PEAK_GBS, "verified": ok, "cpu_port_ms_per_limb": cpu_ms}
+    out["seconds"] = time.perf_counter() - t_start
+    return out
+
+
 def settle(step, sync, min_ms: float = 120.0, max_ms: float = 1500.0, block_ms: float = 20.0, tol: float = 0.01):
     """Untimed steps until the step time is stable: the clocks of a freshly loaded MI355X dip ~25 % for the first
     milliseconds of sustained launches and take ~100 ms to settle, and the driver's short runs
@@ -382,6 +519,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-settle", action="store_true", help="skip the untimed settle loop (A/B: shows the clock transient)")
     ap.add_argument("--no-keyswitch", action="store_true", help="N > 1 only: skip the sharded key-switch leg")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1 only: skip the BASELINE configs 2-5 leg (~40 s)")
     ap.add_argument("--inverse", action="store_true", help="time vintt instead (side metric; headline is forward)")
     ap.add_argument("--keyswitch-child", action="store_true", help=argparse.SUPPRESS)   # internal: one rank of the key-switch leg
     args = ap.parse_args()
@@ -484,6 +622,12 @@ def main() -> int:
         elapsed, dev_ms = float(t[0]), float(t[1])
     clock_ghz = vp.valu_clock_ghz(60.0) if rank == 0 else None   # right behind the timed region: the same thermal state
     vp.close()
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        try:
+            configs = configs_leg(local_rank)
+        except Exception as e:                                   # (the headline line does not depend on this leg)
+            configs = {"error": f"{type(e).__name__}: {e}"}
 
     ks = None
     if dist is not None and world > 1 and not args.no_keyswitch:
@@ -513,7 +657,17 @@ def main() -> int:
             roof["hbm_bound_ntt_per_s"] = hbm_bound_ntt_s
             roof["peak_is"] = "hbm"                          # achieved / peak / frac / traffic are the HBM roofline's whatever binds
             if valu_bound < hbm_bound_ntt_s:
-                roof["bound"] = "valu"                       # the tighter bound ("measure and print both")
+                roof["bound"] = "valu"                       # the tighter of the two textbook bounds ("measure and print both")
+        # what actually binds: the tightest of the design's measured ceilings (the two-pass memory floor, then the VALU bound)
+        ceilings = {k: dict(v) for k, v in CEILINGS.items()}
+        if "valu" in roof:
+            ceilings["valu"] = {"frac": roof["valu"]["as_frac_of_hbm_roofline"], "source": f"this run + profiles/{PMC_SUMMARY}",
+                                "what": "lane-instructions per transform (SQ_INSTS_VALU) at 16 lanes x 1024 SIMDs x the VALU clock measured after the timed region"}
+        roof["ceilings"] = ceilings
+        tight = min(ceilings, key=lambda k: ceilings[k]["frac"])
+        roof["bound"] = "hbm"                                # the binding ceiling is a MEMORY one: two HBM round trips at the rate the access patterns reach
+        roof["binding_ceiling"] = tight
+        roof["frac_of_binding_ceiling"] = roof["frac"] / ceilings[tight]["frac"]
         pm = pmc_summary()
         if pm.get("commit"):
             roof["traffic_commit"] = pm["commit"]
@@ -531,6 +685,8 @@ def main() -> int:
         }
         if ks is not None:
             out["keyswitch"] = ks
+        if configs is not None:
+            out["configs"] = configs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(check=(first_in, primes[0], first_out))
             if out["cpu_baseline"]["gpu_first_limb_equals_cpu"] is False and not os.environ.get("ALOHA_VP_LIB"):

@@ -1,5 +1,5 @@
 import sys, time, json
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests/perf')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np
 from aloha_amd import vp as avp, programs
 import oracle

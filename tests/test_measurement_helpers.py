@@ -55,3 +55,4 @@ def test_handle_runs_on_its_own_device_whatever_is_current():
         assert torch.cuda.current_device() == 0
     for i in range(4):
         assert np.array_equal(got[i], oracle.ntt(a[i], q))
+
