@@ -32,6 +32,8 @@ hipError_t ew(hipStream_t st, EwOp op, u64 *d, const u64 *a, const u64 *b, u64 s
 hipError_t vaut(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 q, u64 k, u64 k_inv);
 // extension: the same automorphism on an NTT-form limb -- out[j] = in[brv(((2 brv(j)+1) k mod 2N - 1)/2)], k mod N
 hipError_t vautn(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 k);
+// extension: out[j] = q where in[j] == 0 and j is a sign-flipped target of the automorphism k, else in[j] (vaut's flipped zero)
+hipError_t vautz(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 q, u64 k, u64 k_inv);
 // cyclic roll: out[j] = in[(j + s) mod N]  (vxu_lane.sv:595,:597)
 hipError_t vroli(hipStream_t st, u64 *out, const u64 *in, unsigned logn, u64 s);
 
@@ -43,7 +45,7 @@ struct EwJob {             // d = op(a, b | s) on n words under modulus m
   ModCtx m;
   int op, pad;
 };
-struct AutJob {            // roll == 0: automorphism gather with (k, k_inv); 1: cyclic roll by k; 2: vautn (NTT-form permutation by k)
+struct AutJob {            // roll == 0: automorphism gather with (k, k_inv); 1: cyclic roll by k; 2: vautn (NTT-form permutation by k); 3: vautz
   u64 *out;
   const u64 *in;
   u64 q;
@@ -117,6 +119,9 @@ struct LimbJob {
   // forward transforms of the fused key-switch phases (N = 2^16, ntt_tile.hip / ntt_ks.hip); 0 = none, else index + 1:
   uint32_t pro;          // SumSrc: the limb to transform is a sum of scaled memory operands, formed in the column pass's loads
   uint32_t epi;          // RowEpi: the row pass ends in a sum of scaled operands with the transform as one of them
+  // inverse transforms at N = 2^16 followed by `vautz` (automorphism exponent zk, its inverse mod N; 0 = none): canonical zeros
+  // at sign-flipped targets leave as q
+  uint32_t zk, zkinv;
 };
 
 // A limb that exists only as  sum_t a_t * s_t + cst  (mod q): the source of a column pass (LimbJob::pro).

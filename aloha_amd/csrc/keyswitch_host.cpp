@@ -55,6 +55,7 @@ inline Ins i_vle(uint32_t vd, uint64_t ptr, uint64_t off) { return enc(0x03, vd,
 inline Ins i_vse(uint32_t vs1, uint64_t ptr, uint64_t off) { return enc(0x07, 0, vs1, 0, 1, (ptr << 48) | off); }
 inline Ins i_vautn(uint32_t vd, uint32_t vs1, uint64_t imm) { return enc(0x1d, vd, vs1, 0, 1, imm); }
 inline Ins i_vaut(uint32_t vd, uint32_t vs1, uint64_t imm) { return enc(0x15, vd, vs1, 0, 1, imm); }
+inline Ins i_vautz(uint32_t vd, uint32_t vs1, uint64_t imm) { return enc(0x21, vd, vs1, 0, 1, imm); }
 inline Ins i_vntt(uint32_t vd, uint32_t vs1) { return enc(0x02, vd, vs1, 0, 0, 0); }
 inline Ins i_vintt(uint32_t vd, uint32_t vs1) { return enc(0x06, vd, vs1, 0, 0, 0); }
 inline Ins i_mul_vv(uint32_t vd, uint32_t a, uint32_t b) { return enc(0x01, vd, a, b, 0, 0); }
@@ -246,7 +247,14 @@ std::vector<Block> blocks_phase1(const Layout &lo, Mode mode, Slots sl) {
     for (uint32_t bi = 0; bi < sl.nb; bi++) {
       const uint64_t x = mode == HOIST ? lo.s_in(1, i, bi) : lo.s_x(i, bi);     // hoisted: c1 itself, not rotated
       b.push_back(i_vle(0, kPtrAbs, lo.off(x))); b.push_back(i_vintt(2, 0)); b.push_back(i_mul_vs(4, 2, c));
-      b.push_back(i_vse(4, kPtrAbs, lo.off(lo.y_slot(j, bi))));
+      if (mode == ROTATE && lo.alpha == 1) {
+        // one prime per digit = the reference's decomposition: the digit must be the reference's vaut(iNTT(c1)) word for
+        // word, which stores a sign-flipped zero as q_d (vxu_lane.sv:598; keyswitch.mem:4-5,:24-25) -- vautz puts those back
+        b.push_back(i_vautz(6, 4, 0));
+        b.push_back(i_vse(6, kPtrAbs, lo.off(lo.y_slot(j, bi))));
+      } else {
+        b.push_back(i_vse(4, kPtrAbs, lo.off(lo.y_slot(j, bi))));
+      }
     }
     bl.push_back(std::move(b));
   }

@@ -142,9 +142,16 @@ __device__ __forceinline__ void col_tile_inv(u64 *sdata, const LimbJob &jb, cons
   for (int kk = 0; kk < 16; kk++) v[kk] = sdata[col * PITCH + slow + 16 * kk];
   const LastScale ls = last_scale<LAST && SC>(jbp, pr);
   inv_radix16<true, INV_MID, LAST>(v, TwStepA{blk}, q, nq, ls.w, ls.ni, ls.nip);
+  const uint32_t zk = (LAST && SC) ? jbp->zk : 0, zkinv = (LAST && SC) ? jbp->zkinv : 0;   // (wave-uniform)
 #pragma unroll
-  for (int kk = 0; kk < 16; kk++)
-    st_stream(&(dst + ((size_t)(16 * kk) << 8))[offA], LAST ? canon_last<SC>(v[kk], q, ls.addc) : v[kk]);
+  for (int kk = 0; kk < 16; kk++) {
+    u64 r = LAST ? canon_last<SC>(v[kk], q, ls.addc) : v[kk];
+    if (LAST && SC && zk && r == 0) {                          // vautz folded in: a zero at a sign-flipped target of the automorphism leaves as q
+      const uint32_t t = ((uint32_t)(16 * kk) << 8) + offA + cg * 16, i = (t * zkinv) & 0xffffu;
+      if (((i * zk) & 0x1ffffu) >= 0x10000u) r = q;
+    }
+    st_stream(&(dst + ((size_t)(16 * kk) << 8))[offA], r);
+  }
 }
 
 // ---- row pass: 256 contiguous points per line, 4 lines per WAVE ------------------------------------------------

@@ -347,7 +347,7 @@ aloha_status run_transforms(aloha_vp *vp, const std::vector<LimbJob> &jobs1, uns
   uint64_t key_hash = 0xcbf29ce484222325ull;         // (one pass over the jobs instead of a memcmp against every cached array)
   for (uint32_t i = 0; i < count; i++) {
     const LimbJob &j = jobs1[i];
-    for (uint64_t x : {(uint64_t)(uintptr_t)j.src, (uint64_t)(uintptr_t)j.dst, ((uint64_t)j.prime << 1) | j.scaled, (uint64_t)j.sc[0], (uint64_t)j.sc[2], (uint64_t)j.addc})
+    for (uint64_t x : {(uint64_t)(uintptr_t)j.src, (uint64_t)(uintptr_t)j.dst, ((uint64_t)j.prime << 1) | j.scaled, (uint64_t)j.sc[0], (uint64_t)j.sc[2], (uint64_t)j.addc, ((uint64_t)j.zk << 32) | j.zkinv})
       key_hash = (key_hash ^ x) * 0x100000001b3ull;
   }
   for (auto &p : vp->plans)
@@ -708,14 +708,14 @@ bool reads_reg(const Decoded &d, unsigned r) {
       if (d.funct3 == 1) return d.vs1 == r;
       if (d.funct3 == 2) return d.vs2 == r;
       return false;
-    case 0x0d: case 0x11: case 0x15: case 0x19: case 0x1d: case 0x02: case 0x06: case 0x07: return d.vs1 == r;
+    case 0x0d: case 0x11: case 0x15: case 0x19: case 0x1d: case 0x21: case 0x02: case 0x06: case 0x07: return d.vs1 == r;
     default: return false;
   }
 }
 
 bool writes_reg(const Decoded &d, unsigned r) {
   switch (d.funct6) {
-    case 0x01: case 0x05: case 0x09: case 0x0d: case 0x11: case 0x15: case 0x19: case 0x1d: case 0x02: case 0x06: case 0x03:
+    case 0x01: case 0x05: case 0x09: case 0x0d: case 0x11: case 0x15: case 0x19: case 0x1d: case 0x21: case 0x02: case 0x06: case 0x03:
       return d.vd == r;
     default: return false;
   }
@@ -1506,7 +1506,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         alias[vd] = nullptr;
         break;
       }
-      case 0x15: case 0x19: case 0x1d: {                           // vaut / vroli  :460-501,:549-558; vautn (0x1d): extension, NTT-form
+      case 0x15: case 0x19: case 0x1d: case 0x21: {                // vaut / vroli  :460-501,:549-558; extensions: vautn (0x1d, NTT form), vautz (0x21, flipped zeros)
         const uint64_t k = (step + imm) & (n - 1);                 // scalar_iconn = csr_step + imm, kept mod N
                                                                    // (vxu_lane.sv:594, vxu_top_tb.sv:603)
         if (funct6 != 0x19 && !((step + imm) & 1))
@@ -1522,8 +1522,8 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           ALOHA_RUN_CK(before_mem_write(z, n, pc + 2));
           if (!can_join(PK_AUT, logn, in, nullptr, z, n)) ALOHA_RUN_CK(flush());
           aloha::k::AutJob jb{};
-          jb.out = z; jb.in = in; jb.q = q; jb.k = (uint32_t)k; jb.roll = funct6 == 0x19 ? 1 : funct6 == 0x1d ? 2 : 0;
-          if (!jb.roll) {
+          jb.out = z; jb.in = in; jb.q = q; jb.k = (uint32_t)k; jb.roll = funct6 == 0x19 ? 1 : funct6 == 0x1d ? 2 : funct6 == 0x21 ? 3 : 0;
+          if (!jb.roll || jb.roll == 3) {
             uint64_t kinv = 1;                                     // k^-1 mod N by Newton iteration (k odd)
             for (int it = 0; it < 5; it++) kinv = kinv * (2 - k * kinv);
             jb.k_inv = (uint32_t)(kinv & (n - 1));
@@ -1544,6 +1544,11 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           for (int it = 0; it < 5; it++) kinv = kinv * (2 - k * kinv);
           kinv &= (n - 1);
           HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::vaut(st, out, in, logn, q, k, kinv); }));
+        } else if (funct6 == 0x21) {
+          uint64_t kinv = 1;
+          for (int it = 0; it < 5; it++) kinv = kinv * (2 - k * kinv);
+          kinv &= (n - 1);
+          HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::vautz(st, out, in, logn, q, k, kinv); }));
         } else if (funct6 == 0x1d) {
           HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::vautn(st, out, in, logn, k); }));
         } else {
@@ -1581,9 +1586,22 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
               at++;
               nx = decode_at(vp, at);
             }
+            // ... `vautz vF, vE, imm` before the store (N = 2^16): a zero at a sign-flipped target becomes q, on the canonical result
+            uint32_t zk = 0, zkinv = 0;
+            if (ok && nx.funct6 == 0x21 && nx.vs1 == e && logn == 16 && ((step + nx.imm) & 1) && at + 1 < ALOHA_IRAM_DEPTH &&
+                (nx.vd == e || dead_from(vp, at + 1, e))) {
+              const uint64_t kz = (step + nx.imm) & (n - 1);
+              uint64_t kinv = 1;
+              for (int it = 0; it < 5; it++) kinv = kinv * (2 - kz * kinv);
+              zk = (uint32_t)kz; zkinv = (uint32_t)(kinv & (n - 1));
+              e = nx.vd;
+              at++;
+              nx = decode_at(vp, at);
+            }
             if (ok && nx.funct6 == 0x07 && nx.vs1 == e && dead_from(vp, at + 1, e)) {
               u64 *zz = mem_rows(vp, nx.imm, false, csr, n / kLanes);
               if (zz) {
+                scaled.zk = zk; scaled.zkinv = zkinv;
                 const uint64_t c = m1.imm >= q ? m1.imm - q : m1.imm;
                 const auto &tt = vp->slots[slot].dev.tw;
                 z = zz; skip = at - pc - 1;
@@ -1615,8 +1633,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           if (skip) {
             scaled.src = src; scaled.dst = z; scaled.prime = slot;
             batch.push_back(scaled);
-            const Decoded m1 = decode_at(vp, pc + 1);
-            lazy[m1.vd].clear(); alias[m1.vd] = nullptr;
+            for (unsigned u = 1; u <= skip; u++) {                 // the registers the folded instructions would have written
+              const Decoded mu_ = decode_at(vp, pc + u);
+              lazy[mu_.vd].clear(); alias[mu_.vd] = nullptr;
+            }
           } else {
             batch.push_back(LimbJob{src, z, slot, 0, {0, 0, 0, 0}, 0});
           }

@@ -28,6 +28,7 @@ F6 = {
     "vfqmul": 0b000001, "vfqadd": 0b000101, "vfqsub": 0b001001, "vfqmod": 0b001101,
     "vcp": 0b010001, "vaut": 0b010101, "vroli": 0b011001,
     "vautn": 0b011101,   # EXTENSION (not in the reference): vaut on an NTT-form limb, a pure permutation
+    "vautz": 0b100001,   # EXTENSION: a zero at a sign-flipped target of the automorphism becomes q (vaut's flipped zero, vxu_lane.sv:598)
     "vntt": 0b000010, "vintt": 0b000110, "vle": 0b000011, "vse": 0b000111,
 }
 F6_NAME = {v: k for k, v in F6.items()}
@@ -153,7 +154,7 @@ def assemble_line(line: str) -> Inst | None:
         raise ValueError(f"bad suffix on {mnem!r}")
     if base in ("vfqmod", "vcp", "vntt", "vintt"):
         return Inst(f6, vd=_reg(ops[0]), vs1=_reg(ops[1]))
-    if base in ("vaut", "vroli", "vautn"):
+    if base in ("vaut", "vroli", "vautn", "vautz"):
         # the shipped key-switch program encodes vaut with funct3 = 001 (keyswitch.mem:6)
         return Inst(f6, vd=_reg(ops[0]), vs1=_reg(ops[1]), funct3=1, imm=_int(ops[2]) if len(ops) > 2 else 0)
     if base == "vle":
@@ -182,7 +183,7 @@ def disassemble_one(i: Inst) -> str:
             return f"{n}.sv v{i.vd}, {i.imm:#x}, v{i.vs2}"
     if n in ("vfqmod", "vcp", "vntt", "vintt"):
         return f"{n} v{i.vd}, v{i.vs1}"
-    if n in ("vaut", "vroli", "vautn"):
+    if n in ("vaut", "vroli", "vautn", "vautz"):
         return f"{n} v{i.vd}, v{i.vs1}, {i.imm:#x}"
     if n in ("vle", "vse"):
         sel, off = i.imm >> 48, i.imm & ((1 << 48) - 1)

@@ -136,18 +136,19 @@ def _setq(q: int) -> List[str]:
     return [f"vsetq {q:#x}", f"vsetiq {barrett_mu(q):#x}"]
 
 
-def program_digits(lo: Layout, reference_shape: bool = True) -> List[str]:
+def program_digits(lo: Layout, reference_shape: bool = False) -> List[str]:
     """Phase 1.  c0 limb i at CT_IN[i], c1 limb i at CT_IN[Lr + i] (i = local index).
 
-    ``reference_shape`` (default): the reference's own sequence (keyswitch.mem:4-7,:24-27,:100-121): iNTT of both
-    components, ``vaut`` in the coefficient domain, NTT of the rotated c0 -- three transforms and two coefficient-domain
-    automorphisms per limb.  ``reference_shape=False`` uses the identity vntt(vaut(x, k)) == vautn(vntt(x), k) (tests):
-    the automorphism is applied to the NTT-form limbs as a pure permutation (``vautn``), the rotated c0 needs no
-    transform at all and the digits are iNTT(vautn(c1)) -- ONE transform per limb.  The two agree word for word unless
-    iNTT(c1) has a ZERO coefficient at a sign-flipped position: the reference's ``vaut`` stores such a zero as q_d
-    (vxu_lane.sv:598) and the basis extension then lifts the digit as q_d instead of 0 under the other moduli (a valid
-    key-switch either way -- the lifts differ by a multiple of q_d -- but different words; probability 2^-60 per
-    coefficient of a real ciphertext).  Parity with the reference comes first, so the exact form is the default."""
+    Default: the identity vntt(vaut(x, k)) == vautn(vntt(x), k) (tests) moves the automorphism onto the NTT-form limbs as a
+    pure permutation (``vautn``): the rotated c0 needs no transform at all and the digits are iNTT(vautn(c1)) -- ONE transform
+    per limb where the reference runs three and two coefficient-domain permutations.  The one place where the two differ in
+    the WORDS is a zero coefficient at a sign-flipped position: the reference's ``vaut`` stores it as q_d (vxu_lane.sv:598),
+    and the basis extension then lifts the digit as q_d, not 0, under the other moduli.  ``vautz`` (an extension, like
+    ``vautn``) puts exactly those q_d back, so the digits -- and with them every output word -- are the reference's
+    (tests: the crafted zero-corner ciphertext, the golden rotates).  The engine folds the ``vautz`` into the inverse
+    transform's last pass.
+    ``reference_shape=True``: the reference's own sequence (keyswitch.mem:4-7,:24-27,:100-121): iNTT of both components,
+    ``vaut`` in the coefficient domain, NTT of the rotated c0."""
     out = [f"vsetvl {64 * lo.n:#x}"]
     if not reference_shape:
         for i, d in enumerate(lo.owned_ct):                     # the automorphism on both NTT-form components
@@ -156,7 +157,8 @@ def program_digits(lo: Layout, reference_shape: bool = True) -> List[str]:
             out += [f"vle v0, abs+{lo.off(lo.ct_in + lo.Lr + i):#x}", "vautn v2, v0, 0x0", f"vse v2, abs+{lo.off(lo.s1 + i):#x}"]
         for i, d in enumerate(lo.owned_ct):                     # digits: the rotated c1 in coefficient form
             out += _setq(lo.moduli[d])
-            out += [f"vle v0, abs+{lo.off(lo.s1 + i):#x}", "vintt v2, v0", f"vse v2, abs+{lo.off(lo.dig_slot(d)):#x}"]
+            out += [f"vle v0, abs+{lo.off(lo.s1 + i):#x}", "vintt v2, v0", "vfqmul.vs v4, v2, 0x1", "vautz v6, v4, 0x0",
+                    f"vse v6, abs+{lo.off(lo.dig_slot(d)):#x}"]
         return out + ["break"]
     for i, d in enumerate(lo.owned_ct):                         # all inverse transforms
         out += _setq(lo.moduli[d])
@@ -404,9 +406,9 @@ class ShardedKeySwitch:
     of phase 2 are loaded one after the other at the same address."""
 
     def __init__(self, vp, n: int, moduli: Sequence[int], special: int, world: int = 1, rank: int = 0,
-                 exchange: Optional[Exchange] = None, base_row: int = 0, reference_shape: bool = True):
-        """``reference_shape=False``: phase 1 with the automorphism in the NTT domain (``program_digits``): a third of the
-        transforms, same words except for zero coefficients at sign-flipped positions."""
+                 exchange: Optional[Exchange] = None, base_row: int = 0, reference_shape: bool = False):
+        """``reference_shape=True``: phase 1 exactly as the reference writes it (``program_digits``): three times the
+        transforms and two coefficient-domain permutations per limb for the same words."""
         self.vp = vp
         self.lo = Layout(n, list(moduli), special, world, rank, base_row)
         self.ex = exchange or Exchange()

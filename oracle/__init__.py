@@ -61,6 +61,7 @@ def lib() -> C.CDLL:
         L.orc_intt.restype = None; L.orc_intt.argtypes = [p, C.c_uint, u64, p]
         L.orc_vaut.restype = None; L.orc_vaut.argtypes = [p, p, C.c_uint, u64, u64]
         L.orc_vautn.restype = None; L.orc_vautn.argtypes = [p, p, C.c_uint, u64]
+        L.orc_vautz.restype = None; L.orc_vautz.argtypes = [p, p, C.c_uint, u64, u64]
         L.orc_set_threads.restype = C.c_int; L.orc_set_threads.argtypes = [C.c_int]
         L.orc_vroli.restype = None; L.orc_vroli.argtypes = [p, p, C.c_uint, u64]
         L.orc_ntt_batch.restype = C.c_int; L.orc_ntt_batch.argtypes = [p, C.c_uint, u64, C.c_uint, C.c_int]
@@ -144,6 +145,13 @@ def vautn(a, k):
     """Extension: the automorphism of ``vaut`` on an NTT-form limb (a permutation, no modulus)."""
     a = _u64(a); out = np.empty_like(a)
     lib().orc_vautn(out.ctypes.data, a.ctypes.data, a.size.bit_length() - 1, k)
+    return out
+
+
+def vautz(a, q, k):
+    """Extension: a zero at a sign-flipped target of the automorphism k becomes q (what ``vaut`` stores there)."""
+    a = _u64(a); out = np.empty_like(a)
+    lib().orc_vautz(out.ctypes.data, a.ctypes.data, a.size.bit_length() - 1, q, k)
     return out
 
 

@@ -281,6 +281,22 @@ void orc_vautn(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t k) {
   }
 }
 
+/* vautz -- EXTENSION (funct6 100001, not in the reference): the one place where the coefficient-domain vaut differs from
+ * the same automorphism carried out in NTT form.  vaut stores a sign-flipped ZERO as q (vxu_lane.sv:598: the raw q - x);
+ * y = vintt(vautn(vntt-form x, k)) holds 0 there.  vautz puts the q back:
+ *     out[t] = q  if in[t] == 0 and t is a sign-flipped target of the automorphism k (t = i*k mod N with i*k mod 2N >= N),
+ *     out[t] = in[t] otherwise (no normalisation),
+ * so that vautz(vintt(vautn(X, k)), k) == vaut(vintt(X), k) word for word for canonical X (tests): the rotate program of
+ * keyswitch.mem:4-7,:24-27 without its coefficient-domain permutation. */
+void orc_vautz(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t q, uint64_t k) {
+  uint64_t n = 1ull << logn;
+  uint64_t ke = k & (n - 1);
+  for (uint64_t i = 0; i < n; i++) {
+    uint64_t t = (i * ke) & (2 * n - 1), pos = t & (n - 1);
+    out[pos] = (t >= n && in[pos] == 0) ? q : in[pos];
+  }
+}
+
 /* vroli.  vxu_lane.sv:595,:597; model vxu_top_tb.sv:619-623: out[(i + N - s) mod N] = in[i] */
 void orc_vroli(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t s) {
   uint64_t n = 1ull << logn;
@@ -490,7 +506,7 @@ int orc_vp_run(orc_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
         for (uint64_t i = 0; i < n; i++) orc_alu(0x05, a[i], 0, 0, q, &d[i], NULL);
         break;
       }
-      case 0x15: case 0x19: case 0x1d: {                          /* vaut / vroli :460-501,:549-558; vautn: extension */
+      case 0x15: case 0x19: case 0x1d: case 0x21: {               /* vaut / vroli :460-501,:549-558; vautn, vautz: extensions */
         uint64_t k = step + imm;                                  /* scalar_iconn = csr_step + imm */
         uint64_t *tmp = (uint64_t *)malloc(n * 8);
         if (!tmp) return ORC_ERR_ARG;
@@ -500,6 +516,9 @@ int orc_vp_run(orc_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
         } else if (funct6 == 0x1d) {
           if (!(k & 1)) { free(tmp); return ORC_ERR_AUT; }
           orc_vautn(tmp, vp->vreg[vs1], logn, k);
+        } else if (funct6 == 0x21) {
+          if (!(k & 1)) { free(tmp); return ORC_ERR_AUT; }
+          orc_vautz(tmp, vp->vreg[vs1], logn, q, k);
         } else {
           orc_vroli(tmp, vp->vreg[vs1], logn, k);
         }

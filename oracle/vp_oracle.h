@@ -67,6 +67,7 @@ void orc_intt(uint64_t *a, unsigned logn, uint64_t q, const uint64_t *itab); /* 
 void orc_vaut(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t q, uint64_t k);
 int orc_set_threads(int n);   /* OpenMP threads of orc_ntt_batch; 0 = all cores; returns the count in effect */
 void orc_vautn(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t k);   /* extension: NTT-domain automorphism */
+void orc_vautz(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t q, uint64_t k);   /* extension: vaut's flipped zeros (q) put back */
 void orc_vroli(uint64_t *out, const uint64_t *in, unsigned logn, uint64_t s);
 /* convenience: table build + transform of `count` limbs stored back to back */
 int orc_ntt_batch(uint64_t *a, unsigned logn, uint64_t q, unsigned count, int inverse);

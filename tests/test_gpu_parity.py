@@ -337,6 +337,36 @@ def test_vaut_vroli_match_oracle(engine, logn):
 
 
 @pytest.mark.parametrize("logn", [10, 13, 16])
+def test_vautz_extension_matches_oracle(engine, logn):
+    """vautz (a zero at a sign-flipped target of the automorphism becomes q): as a batched pass (vle; vautz; vse), in
+    register form, folded into the scaled inverse transform (vintt; vfqmul.vs; [vfqadd.vs;] vautz; vse -- at N = 2^16 inside
+    the last pass's kernel), and the identity it exists for, vautz(vintt(vautn(X))) == vaut(vintt(X)), on the engine."""
+    n = 1 << logn
+    rows = n // 128
+    rng = np.random.default_rng(650 + logn)
+    q = Q0 if logn == 13 else oracle.nth_prime(logn, 0)
+    x = residues(rng, n, q)
+    x[rng.random(n) < 0.6] = 0                                    # many zero coefficients
+    X = oracle.ntt(x, q)
+    c, add = 0x1234567, 0                                         # (a constant added on top would make the zeros non-zero)
+    for k in (3, pow(3, 5, 2 * n), n + 7):
+        prog = f"vsetvl {64 * n:#x}\nvsetq {q:#x}\nvle v0, src0+0x0\nvautz v2, v0, 0x0\nvse v2, rslt+0x0\n" \
+               f"vle v1, src0+0x0\nvautz v3, v1, 0x0\nvse v3, rslt+{8 * n:#x}\nvse v3, rslt+{40 * n:#x}\n" \
+               f"vle v4, src0+{8 * n:#x}\nvautn v6, v4, 0x0\nvintt v8, v6\nvfqmul.vs v10, v8, 0x1\nvautz v12, v10, 0x0\nvse v12, rslt+{16 * n:#x}\n" \
+               f"vle v5, src0+{8 * n:#x}\nvintt v7, v5\nvaut v9, v7, 0x0\nvse v9, rslt+{24 * n:#x}\n" \
+               f"vle v11, src0+{8 * n:#x}\nvintt v13, v11\nvfqmul.vs v15, v13, {c:#x}\nvautz v17, v15, 0x0\nvse v17, rslt+{32 * n:#x}\nbreak"
+        engine.write(SPM, 0, np.concatenate([x, X]))
+        assert _run_asm(engine, prog, src0=0, rslt=2 * rows, step=k) == 0
+        got = engine.read(SPM, 2 * rows, 6 * n).reshape(6, n)
+        assert np.array_equal(got[0], oracle.vautz(x, q, k)), f"batched vautz k={k}"
+        assert np.array_equal(got[1], oracle.vautz(x, q, k)) and np.array_equal(got[5], got[1]), f"register vautz k={k}"   # (stored twice: not the batched form)
+        assert np.array_equal(got[2], got[3]), f"vautz(vintt(vautn)) != vaut(vintt), k={k}"
+        assert np.array_equal(got[3], oracle.vaut(x, q, k))
+        scaled = np.array([(int(v) * c) % q for v in x], dtype=np.uint64)
+        assert np.array_equal(got[4], oracle.vautz(scaled, q, k)), f"scaled inverse + vautz k={k}"
+
+
+@pytest.mark.parametrize("logn", [10, 13, 16])
 def test_vautn_extension_matches_oracle(engine, logn):
     """vautn (NTT-form automorphism): fused batch (vle; vautn; vse), register form, and the identity
     vntt(vaut(x)) == vautn(vntt(x)) evaluated on the engine itself."""

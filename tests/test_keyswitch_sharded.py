@@ -52,11 +52,11 @@ def test_streamed_program_reproduces_golden_rotate():
 
 @pytest.mark.parametrize("reference_shape", [False, True])
 def test_phase1_in_the_ntt_domain_equals_the_reference_shape(reference_shape):
-    """Phase 1 with the automorphism applied to the NTT-form limbs (vautn; one transform per limb) against the reference's
-    own sequence (iNTT, vaut, NTT: keyswitch.mem:4-7,:24-27,:100-121).  Both reproduce the golden rotate and agree on
-    random data; they differ -- and the test pins that they do -- on a ciphertext whose c1 has zero coefficients, where
-    vaut stores a flipped zero as q_d (vxu_lane.sv:598) and the basis extension lifts q_d, not 0, under the other
-    moduli.  That corner is why the reference's shape stays the default."""
+    """Phase 1 with the automorphism applied to the NTT-form limbs (vautn + vautz; one transform per limb: the default)
+    against the reference's own sequence (iNTT, vaut, NTT: keyswitch.mem:4-7,:24-27,:100-121).  Both reproduce the golden
+    rotate, agree on random data -- and agree word for word on a ciphertext whose c1 is mostly ZERO coefficients, where
+    vaut stores a flipped zero as q_d (vxu_lane.sv:598) and the basis extension lifts q_d, not 0, under the other moduli:
+    vautz restores exactly those words (without it the two forms differ there, pinned by the identity test below)."""
     m = manifest()["case0"]
     ct = load(m["kernel1_ct_before_rotate"]).reshape(4, N)
     exp = load(m["kernel1_ct_after_rotate"]).reshape(2, 2, N)
@@ -73,7 +73,7 @@ def test_phase1_in_the_ntt_domain_equals_the_reference_shape(reference_shape):
     sparse[2, :] = oracle.ntt(np.concatenate([np.arange(1, 9, dtype=np.uint64), np.zeros(N - 8, np.uint64)]), Q0)
     ref = keyswitch.ShardedKeySwitch(oracle.OracleVP(), N, [Q0, Q1], P, reference_shape=True)
     ref.load_key(ksk); ref.load_ct(sparse); ref.rotate(k)
-    assert np.array_equal(rotate(sparse), ref.read_out()) == reference_shape
+    assert np.array_equal(rotate(sparse), ref.read_out())
     n, L = 1024, 3
     mods, special, rct, rksk = _random_case(n, L, 11)
     outs = []
@@ -363,3 +363,21 @@ def test_baseline_config5_full_size_reference_algorithm_rotate_gpu_equals_oracle
     with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
         got = run(vp)
     assert np.array_equal(got, exp)
+
+
+def test_vautz_restores_the_flipped_zeros_of_vaut():
+    """The identity that pins the vautz extension: vautz(vintt(vautn(X, k)), k) == vaut(vintt(X), k) word for word, zeros at
+    sign-flipped targets included (q there, vxu_lane.sv:598), for X = vntt of a polynomial with many zero coefficients --
+    and without vautz the two sides differ exactly at those positions."""
+    for logn, k in ((10, 5), (13, pow(3, 2, 1 << 14)), (13, pow(3, 8, 1 << 14) + (1 << 13))):
+        n = 1 << logn
+        q = Q0 if logn == 13 else oracle.nth_prime(logn, 0)
+        rng = np.random.default_rng(logn + k)
+        x = rng.integers(0, q, n, dtype=np.uint64)
+        x[rng.random(n) < 0.5] = 0
+        X = oracle.ntt(x, q)
+        want = oracle.vaut(oracle.intt(X, q), q, k)
+        mid = oracle.intt(oracle.vautn(X, k), q)
+        assert np.array_equal(oracle.vautz(mid, q, k), want)
+        diff = np.nonzero(mid != want)[0]
+        assert len(diff) and np.all(mid[diff] == 0) and np.all(want[diff] == q)
