@@ -326,7 +326,7 @@ def settle(step, sync, min_ms: float = 120.0, max_ms: float = 1500.0, block_ms: 
         prev = cur
 
 
-def keyswitch_leg(dist, backend, rank, world, local_rank):
+def keyswitch_leg(dist, backend, rank, world, local_rank, batch=1):
     """BASELINE config 4 on the ranks of this run: HMult + relinearisation at N = 2^16, L = 24, hybrid key-switch
     with alpha = K = 4 (aloha_amd/hybrid.py), RNS limbs sharded limb j -> rank j mod world, the digit all-gather and
     the mod-down all-gather over torch.distributed (keyswitch.mem:4-43,:80-83 are the steps they parallelise).  Timed
@@ -344,20 +344,21 @@ def keyswitch_leg(dist, backend, rank, world, local_rank):
             kl = np.random.default_rng(7000 + j).integers(0, (mods + specials)[j], lo.dnum * 2 * N, dtype=np.uint64)
             ks.vp.write(1, (jl * lo.dnum) * 2 * lo.rows, kl)
         ct = np.stack([np.random.default_rng(539 + j).integers(0, mods[j % L], N, dtype=np.uint64) for j in range(2 * L)])
-        ks.load_ct(ct); ks.load_ct_b(ct[::-1].copy())
+        for b in range(batch):                                   # ciphertext b = the same words rolled by b (cheap, distinct)
+            ks.load_ct(np.roll(ct, b, axis=1), b); ks.load_ct_b(np.roll(ct[::-1], b, axis=1).copy(), b)
 
     res = {"config": f"HMult + relinearisation, N=2^16, L={L} (+{alpha} special), hybrid key-switch alpha={alpha}, limbs sharded j -> rank j mod {world}",
-           "n_gpus": world, "reps": reps, "backend": backend}
+           "n_gpus": world, "reps": reps, "backend": backend, "batch": batch}
     t_of = lambda *a: torch.tensor(list(a), dtype=torch.float64, device="cuda" if on_gpu else "cpu")
     out = None
     for mode in ("collective", "p2p"):
         stream = torch.cuda.Stream()
-        lo = hybrid.HybridLayout(N, mods, specials, alpha, world, rank)
+        lo = hybrid.HybridLayout(N, mods, specials, alpha, world, rank, batch=batch)
         ex = keyswitch.Exchange(tensor_of=keyswitch.device_tensor if on_gpu else None, stream=stream if on_gpu else None,
                                 p2p=(mode == "p2p"))
         with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=max(1, lo.ksk_limbs * lo.rows), max_log_n=LOGN, device=local_rank,
                     stream=stream.cuda_stream) as vp:
-            ks = hybrid.HybridKeySwitch(vp, N, mods, specials, alpha, world=world, rank=rank, exchange=ex)
+            ks = hybrid.HybridKeySwitch(vp, N, mods, specials, alpha, world=world, rank=rank, exchange=ex, batch=batch)
             load(ks, lo)
             ks.multiply(); vp.sync()
             dist.barrier(); torch.cuda.synchronize()
@@ -371,16 +372,17 @@ def keyswitch_leg(dist, backend, rank, world, local_rank):
             res[f"ms_{mode}"] = float(t[0]) / reps * 1e3
             res[f"bytes_sent_per_rank_{mode}"] = (ex.bytes_sent - sent0) // reps
             res[f"bytes_received_per_rank_{mode}"] = (ex.bytes_received - recv0) // reps
+            got = np.stack([ks.read_out(b) for b in range(batch)])
             if out is None:
-                out = ks.read_out()
+                out = got
                 owned = list(lo.owned_ct)
             else:                                                # both exchange forms must give the same words
-                same = bool(np.array_equal(out, ks.read_out()))
+                same = bool(np.array_equal(out, got))
                 t = t_of(1.0 if same else 0.0); dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 res["p2p_equals_collective"] = bool(t[0] > 0.5)
-    lo1 = hybrid.HybridLayout(N, mods, specials, alpha, 1, 0)
+    lo1 = hybrid.HybridLayout(N, mods, specials, alpha, 1, 0, batch=batch)
     with avp.VP(spm_rows=lo1.spm_rows_needed, ksk_rows=lo1.ksk_limbs * lo1.rows, max_log_n=LOGN, device=local_rank) as vp1:
-        ks1 = hybrid.HybridKeySwitch(vp1, N, mods, specials, alpha, world=1, rank=0, exchange=keyswitch.Exchange())
+        ks1 = hybrid.HybridKeySwitch(vp1, N, mods, specials, alpha, world=1, rank=0, exchange=keyswitch.Exchange(), batch=batch)
         load(ks1, lo1)
         ks1.multiply(); vp1.sync()
         t0 = time.perf_counter()
@@ -388,11 +390,12 @@ def keyswitch_leg(dist, backend, rank, world, local_rank):
             ks1.multiply()
         vp1.sync()
         res["ms_single_rank"] = (time.perf_counter() - t0) / reps * 1e3      # the same operation on ONE GPU, for the speed-up
-        ref = ks1.read_out()
-    ok = all(np.array_equal(out[:, i], ref[:, j]) for i, j in enumerate(owned))
+        ref = np.stack([ks1.read_out(b) for b in range(batch)])
+    ok = all(np.array_equal(out[:, :, i], ref[:, :, j]) for i, j in enumerate(owned))
     t = t_of(1.0 if ok else 0.0); dist.all_reduce(t, op=dist.ReduceOp.MIN)
     res["verified"] = bool(t[0] > 0.5)
     res["ms"] = min(res["ms_collective"], res["ms_p2p"])
+    res["ms_per_ciphertext"] = res["ms"] / batch
     res["exchange"] = "p2p" if res["ms_p2p"] < res["ms_collective"] else "collective"
     return res
 
@@ -469,39 +472,61 @@ def keyswitch_child() -> int:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=timedelta(seconds=120))
     else:                                                        # the C host brings its own RCCL communicator: gloo carries the id and the timings
         dist.init_process_group(backend="gloo", timeout=timedelta(seconds=120))
-    res = keyswitch_leg_c_host(dist, rank, world, local_rank) if c_host else keyswitch_leg(dist, backend, rank, world, local_rank)
+    if c_host:
+        res = keyswitch_leg_c_host(dist, rank, world, local_rank)
+    else:
+        # one ciphertext per call, and four: a single key-switch spread over 8 GPUs leaves 3-4 moduli per rank and is
+        # bound by kernel latency (rank 0's share 0.11 ms against 0.28 / 8 ideal); `batch` ciphertexts under one key
+        # keep the per-rank launches large enough to fill a GPU
+        res = keyswitch_leg(dist, backend, rank, world, local_rank, batch=1)
+        res["batch4"] = keyswitch_leg(dist, backend, rank, world, local_rank, batch=4)
     if rank == 0:
         print("KEYSWITCH_JSON " + json.dumps(res), flush=True)
     dist.destroy_process_group()
     return 0
 
 
-def keyswitch_in_children(rank: int, timeout_s: float = 200.0):
+def keyswitch_child_env(environ: dict, mode: str, port_shift: int) -> dict:
+    """Environment of one rank of a key-switch child group: the rank's own RANK / LOCAL_RANK / WORLD_SIZE, a rendezvous
+    port of its own (derived from the run's MASTER_PORT, different for each of the groups a run creates: the run itself,
+    the `torch` child group, the `c_host` child group), and none of the elastic agent's variables (under torchrun the
+    agent's store serves MASTER_PORT only: without them rank 0 of the child group hosts its own)."""
+    env = {k: v for k, v in environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str((int(environ.get("MASTER_PORT", "29500")) + port_shift) % 60000 + 2048)
+    env["ALOHA_KS_CHILD_MODE"] = mode
+    return env
+
+
+KS_CHILD_PORT_SHIFTS = {"torch": 1009, "c_host": 2027}
+
+
+def keyswitch_in_children(rank: int, budget_s: float = 90.0):
     """The sharded key-switch leg runs in CHILD processes with a rendezvous of their own (every rank of this run starts
     one and waits for it with a time limit): its collectives have never met more than one GPU at the time of writing,
-    and a failure or a hang there must not cost the headline line -- it becomes {"error": ...} in the `keyswitch` object."""
+    and a failure or a hang there must not cost the headline line -- it becomes {"error": ...} in the `keyswitch` object.
+    ONE budget for the whole leg: the second child gets what the first left, and is skipped if the first timed out."""
     import subprocess
+    t_end = time.monotonic() + budget_s
 
-    def child(mode: str, port_shift: int):
-        env = dict(os.environ)
-        env["MASTER_PORT"] = str((int(os.environ.get("MASTER_PORT", "29500")) + port_shift) % 60000 + 2048)
-        env["ALOHA_KS_CHILD_MODE"] = mode
-        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:   # (under torchrun the agent's store serves MASTER_PORT only:
-            env.pop(k)                                                #  without these rank 0 of the child group hosts its own)
+    def child(mode: str):
+        left = t_end - time.monotonic()
+        if left < 10.0:
+            return {"error": "skipped: the leg's time budget was spent"}
+        env = keyswitch_child_env(dict(os.environ), mode, KS_CHILD_PORT_SHIFTS[mode])
         try:
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--keyswitch-child"], env=env, capture_output=True, text=True,
-                               timeout=timeout_s)
+                               timeout=left)
         except subprocess.TimeoutExpired:
-            return {"error": f"did not finish within {timeout_s:.0f} s (killed)"}
+            return {"error": f"did not finish within {left:.0f} s (killed)", "timed_out": True}
         for line in p.stdout.splitlines():
             if line.startswith("KEYSWITCH_JSON "):
                 return json.loads(line[len("KEYSWITCH_JSON "):])
         return {"error": f"exited with code {p.returncode}", "stderr_tail": p.stderr[-600:]}
 
-    res = child("torch", 1009)                                   # Python host + torch.distributed (collective and point-to-point)
+    res = child("torch")                                         # Python host + torch.distributed (collective and point-to-point; batch 1 and 4)
     c_host = None
     if os.environ.get("ALOHA_BENCH_BACKEND", "nccl") == "nccl":  # (two ranks of a rehearsal on ONE GPU cannot form an RCCL communicator)
-        c_host = child("c_host", 2027)
+        c_host = {"error": "skipped: the first child timed out"} if res.get("timed_out") else child("c_host")
     if rank != 0:
         return None
     if c_host is not None:
@@ -631,6 +656,9 @@ def main() -> int:
 
     ks = None
     if dist is not None and world > 1 and not args.no_keyswitch:
+        if rank == 0:                                            # the headline is on record before the leg that has never met N GPUs starts
+            print("BENCH_HEADLINE " + json.dumps({"value": world * B * args.steps / elapsed, "unit": "NTT/s", "n_gpus": world,
+                                                  "ms_per_step": elapsed / args.steps * 1e3}), file=sys.stderr, flush=True)
         ks = keyswitch_in_children(rank)
 
     if rank == 0:

@@ -118,3 +118,41 @@ def test_bench_self_launch_reports_a_rank_killed_by_a_signal():
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 128 + int(signal.SIGABRT), (p.returncode, p.stderr[-400:])
     assert time.monotonic() - t0 < 100                             # the sleeping siblings (120 s) were terminated
+
+
+def test_bench_eight_rank_launch_and_the_three_rendezvous():
+    """First contact with an 8-GPU node, rehearsed without one: `bench.py --gpus 8` starts 8 ranks with distinct
+    RANK / LOCAL_RANK and ONE rendezvous; the two key-switch child groups each get a rendezvous port of their own, the same
+    on every rank, different from the run's and from each other, with the elastic agent's variables removed."""
+    import importlib.util
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ALOHA_BENCH_ECHO"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        lines = [l for l in p.stderr.splitlines() if l.startswith("bench.py rank ")]
+        assert sorted(int(l.split()[2]) for l in lines) == list(range(8))
+        assert sorted(int(l.split(" local ")[1].split()[0]) for l in lines) == list(range(8))
+        assert len({l.split("master ")[1] for l in lines}) == 1 and all(" of 8 " in l for l in lines)
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ports = set()
+    for base in ("29500", "61234", "1024"):
+        per_rank = []
+        for r in range(8):
+            run_env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": "8", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": base,
+                       "TORCHELASTIC_RUN_ID": "x", "TORCHELASTIC_USE_AGENT_STORE": "True"}
+            envs = {m: bench.keyswitch_child_env(run_env, m, bench.KS_CHILD_PORT_SHIFTS[m]) for m in ("torch", "c_host")}
+            for m, e in envs.items():
+                assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["ALOHA_KS_CHILD_MODE"]) == (str(r), str(r), "8", m)
+                assert not any(k.startswith("TORCHELASTIC_") for k in e) and 2048 <= int(e["MASTER_PORT"]) < 62048
+            per_rank.append((envs["torch"]["MASTER_PORT"], envs["c_host"]["MASTER_PORT"]))
+        assert len(set(per_rank)) == 1                               # every rank derives the same two ports
+        a, b = per_rank[0]
+        assert len({a, b, base}) == 3
+        ports.add((a, b))
+    assert len(ports) == 3
