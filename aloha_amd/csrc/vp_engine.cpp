@@ -94,6 +94,7 @@ struct aloha_vp {
   uint32_t flags = 0;
   uint64_t spm_rows = 0, ksk_rows = 0;
   unsigned max_logn = 16;
+  uint32_t iram_depth = ALOHA_IRAM_DEPTH;            // instruction ROM words (inst_rom.v:32-35: 4096; deeper on request)
   u64 *d_spm = nullptr, *d_ksk = nullptr, *d_vreg = nullptr, *d_scratch = nullptr;
   // architectural state (vxu_top.sv:106-118)
   uint64_t vl_bits = 0, q = 0, mu = 0;
@@ -473,6 +474,7 @@ aloha_status aloha_vp_get_config(const aloha_vp *vp, aloha_vp_config *out) {
   if (!vp || !out) return ALOHA_ERR_ARG;
   out->abi_version = ALOHA_VP_ABI_VERSION; out->device = vp->device; out->spm_rows = vp->spm_rows; out->ksk_rows = vp->ksk_rows;
   out->max_log_n = vp->max_logn; out->flags = vp->flags; out->stream = (void *)vp->stream;
+  out->iram_depth = vp->iram_depth; out->reserved = 0;
   return ALOHA_OK;
 }
 
@@ -510,6 +512,7 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   *out = nullptr;
   if (cfg->abi_version != ALOHA_VP_ABI_VERSION) return ALOHA_ERR_ARG;
   if (cfg->max_log_n < 10 || cfg->max_log_n > 16) return ALOHA_ERR_ARG;
+  if (cfg->iram_depth && (cfg->iram_depth < ALOHA_IRAM_DEPTH || cfg->iram_depth > ALOHA_IRAM_DEPTH_MAX)) return ALOHA_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return ALOHA_ERR_DEVICE;
   hipDeviceProp_t prop;
@@ -521,6 +524,7 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   vp->spm_rows = cfg->spm_rows;
   vp->ksk_rows = cfg->ksk_rows;
   vp->max_logn = cfg->max_log_n;
+  vp->iram_depth = cfg->iram_depth ? cfg->iram_depth : ALOHA_IRAM_DEPTH;
   if (const char *e = getenv("ALOHA_NTT_CHUNK")) vp->chunk_limbs = (uint32_t)strtoul(e, nullptr, 10);
   vp->run_cache_on = !getenv("ALOHA_NO_RUN_CACHE");          // (A/B switch: every run goes through the sequencer again)
   if (const char *e = getenv("ALOHA_MAX_TWIDDLE_SETS")) vp->max_slots = std::min(kMaxPrimes, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));
@@ -542,8 +546,8 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
     if (!(m && !strcmp(m, "persistent"))) vp->fused_wgs = 0;
   }
 #endif
-  vp->inst.assign(ALOHA_IRAM_DEPTH, 0);
-  vp->imm.assign(ALOHA_IRAM_DEPTH, 0);
+  vp->inst.assign(vp->iram_depth, 0);
+  vp->imm.assign(vp->iram_depth, 0);
   auto bail = [&](const char *what) {
     fprintf(stderr, "aloha_vp_create: %s failed\n", what);
     aloha_vp_destroy(vp);
@@ -635,7 +639,7 @@ int aloha_vp_device(const aloha_vp *vp) { return vp ? vp->device : -1; }
 
 aloha_status aloha_vp_load_isram(aloha_vp *vp, uint32_t base_pc, const uint32_t *words, uint32_t n) {
   if (!vp || !words) return ALOHA_ERR_ARG;
-  if (base_pc > ALOHA_IRAM_DEPTH || n > ALOHA_IRAM_DEPTH - base_pc) return fail(vp, ALOHA_ERR_ADDR, "isram [%u, +%u) outside the %u-word ROM", base_pc, n, ALOHA_IRAM_DEPTH);
+  if (base_pc > vp->iram_depth || n > vp->iram_depth - base_pc) return fail(vp, ALOHA_ERR_ADDR, "isram [%u, +%u) outside the %u-word ROM", base_pc, n, vp->iram_depth);
   for (uint32_t i = 0; i < n; i++) {
     vp->inst[base_pc + i] = words[3 * i];
     vp->imm[base_pc + i] = ((uint64_t)words[3 * i + 1] << 32) | words[3 * i + 2];
@@ -723,7 +727,7 @@ bool writes_reg(const Decoded &d, unsigned r) {
 
 // is register r dead from pc on (overwritten or program end before any read)?
 bool dead_from(const aloha_vp *vp, uint32_t pc, unsigned r) {
-  for (; pc < ALOHA_IRAM_DEPTH; pc++) {
+  for (; pc < vp->iram_depth; pc++) {
     const Decoded d = decode_at(vp, pc);
     if (d.funct6 == 0x10) return true;
     if (reads_reg(d, r)) return false;
@@ -768,10 +772,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   aloha_vp::RunPlan fresh;
   uint64_t run_hash = 0;
   const uint64_t instructions0 = vp->stats.instructions;
-  if (fuse && vp->run_cache_on && pc < ALOHA_IRAM_DEPTH) {
+  if (fuse && vp->run_cache_on && pc < vp->iram_depth) {
     uint32_t end = pc;
-    while (end < ALOHA_IRAM_DEPTH && ((vp->inst[end] >> 26) & 0x3f) != 0x10) end++;      // break  expander.v:141-151
-    if (end < ALOHA_IRAM_DEPTH) {
+    while (end < vp->iram_depth && ((vp->inst[end] >> 26) & 0x3f) != 0x10) end++;      // break  expander.v:141-151
+    if (end < vp->iram_depth) {
       const uint32_t len = end - pc + 1;
       uint64_t h = 0xcbf29ce484222325ull;
       auto mix = [&](uint64_t x) { h = (h ^ x) * 0x100000001b3ull; };
@@ -850,7 +854,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         fresh_sets.insert(std::make_pair(q_scan, (uint64_t)ln));
     };
     note();                                                   // the pair inherited from the previous run: a program may transform before its first vsetq
-    for (uint32_t i = pc; i < ALOHA_IRAM_DEPTH; i++) {
+    for (uint32_t i = pc; i < vp->iram_depth; i++) {
       const Decoded d = decode_at(vp, i);                     // (the decoder of the sequencer below: funct6 selects, expander.v:123-130)
       if (d.funct6 == 0x10) break;
       if (d.funct6 == 0x08) q_scan = d.imm;
@@ -1005,7 +1009,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       for (const auto &t : lazy[r]) refers = refers || (t.first && overlap(t.first, p_, n_)) || (t.second && overlap(t.second, p_, n_));
       if (refers && !dead_from(vp, pc, r)) return true;
     }
-    for (uint32_t i = pc; i < ALOHA_IRAM_DEPTH; i++) {
+    for (uint32_t i = pc; i < vp->iram_depth; i++) {
       const Decoded d = decode_at(vp, i);
       if (d.funct6 == 0x10) return false;
       if (d.funct6 == 0x04) return true;                      // the vector length changes: not followed further
@@ -1349,7 +1353,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
 #define ALOHA_RUN_CK(expr) do { aloha_status s_ = (expr); if (s_) { (void)flush(); return s_; } } while (0)
 
   for (;; pc++) {
-    if (pc >= ALOHA_IRAM_DEPTH) ALOHA_RUN_FAIL(ALOHA_ERR_NOBREAK, "no break before the end of the ROM");
+    if (pc >= vp->iram_depth) ALOHA_RUN_FAIL(ALOHA_ERR_NOBREAK, "no break before the end of the ROM");
     const Decoded d = decode_at(vp, pc);
     const unsigned funct6 = d.funct6, vs2 = d.vs2, vs1 = d.vs1, funct3 = d.funct3, vd = d.vd;
     const uint64_t imm = d.imm;
@@ -1368,7 +1372,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     // a following `vse vd, Z` this instruction may write to directly
     auto direct_store = [&](u64 **out) -> aloha_status {
       *out = nullptr;
-      if (!fuse || pc + 1 >= ALOHA_IRAM_DEPTH) return ALOHA_OK;
+      if (!fuse || pc + 1 >= vp->iram_depth) return ALOHA_OK;
       const Decoded nx = decode_at(vp, pc + 1);
       if (nx.funct6 != 0x07 || nx.vs1 != vd || !dead_from(vp, pc + 2, vd)) return ALOHA_OK;
       u64 *z = mem_rows(vp, nx.imm, false, csr, n / kLanes);
@@ -1574,21 +1578,21 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         // instead of a transform, a pass over the limb and a store.  Tile / single-pass kernels only (N >= 2^12).
         unsigned skip = 0;                                         // instructions consumed besides the vintt and the vse
         LimbJob scaled{};
-        if (!z && inv && fuse && logn >= 12 && !(vp->flags & ALOHA_FLAG_RADIX2_ONLY) && pc + 2 < ALOHA_IRAM_DEPTH) {
+        if (!z && inv && fuse && logn >= 12 && !(vp->flags & ALOHA_FLAG_RADIX2_ONLY) && pc + 2 < vp->iram_depth) {
           const Decoded m1 = decode_at(vp, pc + 1);
           if (m1.funct6 == 0x01 && m1.funct3 == 1 && m1.vs1 == vd && m1.imm < 2 * q) {
             unsigned e = m1.vd, at = pc + 2;
             uint64_t addc = 0;
             bool ok = (e == vd) || dead_from(vp, pc + 2, vd);
             Decoded nx = decode_at(vp, at);
-            if (ok && nx.funct6 == 0x05 && nx.funct3 == 1 && nx.vs1 == e && nx.vd == e && nx.imm < 2 * q && at + 1 < ALOHA_IRAM_DEPTH) {
+            if (ok && nx.funct6 == 0x05 && nx.funct3 == 1 && nx.vs1 == e && nx.vd == e && nx.imm < 2 * q && at + 1 < vp->iram_depth) {
               addc = nx.imm >= q ? nx.imm - q : nx.imm;
               at++;
               nx = decode_at(vp, at);
             }
             // ... `vautz vF, vE, imm` before the store (N = 2^16): a zero at a sign-flipped target becomes q, on the canonical result
             uint32_t zk = 0, zkinv = 0;
-            if (ok && nx.funct6 == 0x21 && nx.vs1 == e && logn == 16 && ((step + nx.imm) & 1) && at + 1 < ALOHA_IRAM_DEPTH &&
+            if (ok && nx.funct6 == 0x21 && nx.vs1 == e && logn == 16 && ((step + nx.imm) & 1) && at + 1 < vp->iram_depth &&
                 (nx.vd == e || dead_from(vp, at + 1, e))) {
               const uint64_t kz = (step + nx.imm) & (n - 1);
               uint64_t kinv = 1;

@@ -175,12 +175,13 @@ class HybridKeySwitch:
         self.lo = lo = HybridLayout(n, moduli, specials, alpha, world, rank, base_row, batch)
         self.ex = exchange or Exchange()
         # a PLAN of the C host (no engine attached): the one generator of the phase programs
+        self._rom = int(getattr(vp, "iram_depth", isa.IRAM_DEPTH))  # the engine's instruction ROM: 4096 words unless it was created deeper
         self._plan = cks.KeySwitch(None, n.bit_length() - 1, moduli, specials, alpha, world, rank, batch, base_row,
-                                   flags=cks.REFERENCE_PHASE1 if reference_phase1 else 0)
+                                   flags=cks.REFERENCE_PHASE1 if reference_phase1 else 0, rom_depth=self._rom)
         assert (self._plan.owned_ct, self._plan.owned_all, self._plan.dnum) == (lo.owned_ct, lo.owned_all, lo.dnum)
         self._p = {name: self._fetch(name) for name in cks.PHASES}
         total = sum(len(w) for ps in self._p.values() for w in ps)
-        self._resident = total <= isa.IRAM_DEPTH
+        self._resident = total <= self._rom
         self._pc = {}
         if self._resident:
             pc = 0

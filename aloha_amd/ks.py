@@ -17,7 +17,7 @@ from . import vp as avp
 class _KsConfig(C.Structure):
     _fields_ = [("log_n", C.c_uint32), ("L", C.c_uint32), ("K", C.c_uint32), ("alpha", C.c_uint32), ("world", C.c_uint32),
                 ("rank", C.c_uint32), ("batch", C.c_uint32), ("flags", C.c_uint32), ("moduli", C.POINTER(C.c_uint64)),
-                ("specials", C.POINTER(C.c_uint64)), ("base_row", C.c_uint64)]
+                ("specials", C.POINTER(C.c_uint64)), ("base_row", C.c_uint64), ("rom_depth", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class _KsInfo(C.Structure):
@@ -71,11 +71,11 @@ def _lib():
 REFERENCE_PHASE1 = 1
 
 
-def _config(log_n, moduli, specials, alpha, world, rank, batch, base_row, flags=0):
+def _config(log_n, moduli, specials, alpha, world, rank, batch, base_row, flags=0, rom_depth=0):
     m = (C.c_uint64 * len(moduli))(*[int(q) for q in moduli])
     s = (C.c_uint64 * len(specials))(*[int(q) for q in specials])
     cfg = _KsConfig(log_n=log_n, L=len(moduli), K=len(specials), alpha=alpha, world=world, rank=rank, batch=batch, flags=flags,
-                    moduli=m, specials=s, base_row=base_row)
+                    moduli=m, specials=s, base_row=base_row, rom_depth=rom_depth)
     return cfg, (m, s)
 
 
@@ -102,9 +102,10 @@ class KeySwitch:
     """One rank's share of the L-limb key-switch, run by the C host.  ``vp=None`` gives a plan (programs only)."""
 
     def __init__(self, vp: Optional[avp.VP], log_n: int, moduli: Sequence[int], specials: Sequence[int], alpha: int,
-                 world: int = 1, rank: int = 0, batch: int = 1, base_row: int = 0, flags: int = 0):
+                 world: int = 1, rank: int = 0, batch: int = 1, base_row: int = 0, flags: int = 0, rom_depth: int = 0):
+        """``rom_depth``: instruction ROM words the phase programs may fill (0: the handle's ROM, or 4096 for a plan)."""
         self._L = _lib()
-        cfg, self._keep = _config(log_n, moduli, specials, alpha, world, rank, batch, base_row, flags)
+        cfg, self._keep = _config(log_n, moduli, specials, alpha, world, rank, batch, base_row, flags, rom_depth)
         h = C.c_void_p()
         rc = self._L.aloha_ks_create(vp._h if vp is not None else None, C.byref(cfg), C.byref(h))
         if rc:

@@ -51,7 +51,7 @@ class AlohaError(RuntimeError):
 class _Config(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("spm_rows", C.c_uint64),
                 ("ksk_rows", C.c_uint64), ("max_log_n", C.c_uint32), ("flags", C.c_uint32),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("iram_depth", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class _Stats(C.Structure):
@@ -121,10 +121,13 @@ class VP:
     """One VP engine on one GPU (one process per GPU; handles are single-threaded)."""
 
     def __init__(self, spm_rows: int = 1 << 16, ksk_rows: int = 1 << 16, max_log_n: int = 16,
-                 device: int = 0, flags: int = 0, stream: int = 0):
+                 device: int = 0, flags: int = 0, stream: int = 0, iram_depth: int = 4096):
+        """``iram_depth``: instruction ROM words -- 4096 as in the reference (vp_defines.vh:31), up to 65536 for programs that
+        do not fit (a whole key-switch phase at L = 32)."""
         L = load_library()
         cfg = _Config(abi_version=L.aloha_vp_abi_version(), device=device, spm_rows=spm_rows,
-                      ksk_rows=ksk_rows, max_log_n=max_log_n, flags=flags, stream=stream or None)
+                      ksk_rows=ksk_rows, max_log_n=max_log_n, flags=flags, stream=stream or None, iram_depth=iram_depth)
+        self.iram_depth = iram_depth
         h = C.c_void_p()
         rc = L.aloha_vp_create(C.byref(cfg), C.byref(h))
         if rc:
@@ -200,7 +203,7 @@ class VP:
         c = _Config()
         self._chk(self._L.aloha_vp_get_config(self._h, C.byref(c)))
         return {"device": int(c.device), "spm_rows": int(c.spm_rows), "ksk_rows": int(c.ksk_rows),
-                "max_log_n": int(c.max_log_n), "flags": int(c.flags)}
+                "max_log_n": int(c.max_log_n), "flags": int(c.flags), "iram_depth": int(c.iram_depth)}
 
     # -- batched transforms -------------------------------------------------------------------
     def ntt_rows(self, space: int, dst_row: int, src_row: int, log_n: int, moduli: Sequence[int],

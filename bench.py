@@ -41,7 +41,7 @@ import torch  # noqa: E402
 LOGN = 16
 N = 1 << LOGN
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = "r02_pmc_summary.json"     # written by tools/collect_pmc.sh; its "commit" field says for which kernels
+PMC_SUMMARY = "r03_pmc_summary.json"     # written by tools/collect_pmc.sh; its "commit" field says for which kernels
 
 
 def pmc_summary():
@@ -244,7 +244,8 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
         mods = [avp.nth_prime(logn, i) for i in range(L)]
         specials = [avp.nth_prime(logn, L + k) for k in range(alpha)]
         lo = hybrid.HybridLayout(n, mods, specials, alpha)
-        sizes = dict(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows)
+        # (instruction ROM of 16384 words on both machines: the mid phase of L = 32 needs ~6700, the reference's 4096 would cut it in two)
+        sizes = dict(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, iram_depth=16384)
         k = pow(3, 5, 2 * n)
         with avp.VP(max_log_n=16, device=device, **sizes) as vp:
             hs = hybrid.HybridKeySwitch(vp, n, mods, specials, alpha)
@@ -274,6 +275,7 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
             t = timeit(run, vp.sync, 10)
             by = acc.keyswitch_bytes(n, L, alpha, lo.dnum, op)
             res.update({"ms": t * 1e3, "launches": (vp.stats()["kernel_launches"] - l0) / 11, "L": L, "K": alpha, "alpha": alpha, "dnum": lo.dnum,
+                        "iram_depth": 16384,
                         "algorithmic_bytes": by, "GBps": by["survey_total"] / t / 1e9, "frac": by["survey_total"] / t / 1e9 / HBM_PEAK_GBS,
                         "frac_lean": by["lean_total"] / t / 1e9 / HBM_PEAK_GBS})
             return res

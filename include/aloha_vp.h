@@ -60,7 +60,9 @@ typedef enum {
 
 enum { ALOHA_SPACE_SPM = 0, ALOHA_SPACE_KSK = 1 };
 #define ALOHA_ROW_BYTES 1024u   /* 128 lanes x 8 B: vp_defines.vh:25,:62 */
-#define ALOHA_IRAM_DEPTH 4096u  /* vp_defines.vh:31 */
+#define ALOHA_IRAM_DEPTH 4096u  /* vp_defines.vh:31: the reference's instruction ROM, and the default here */
+#define ALOHA_IRAM_DEPTH_MAX 65536u /* aloha_vp_config.iram_depth: a deeper ROM (same word format, same entry points) for programs the
+                                       reference's 4096 words cannot hold in one piece -- a key-switch phase at L = 32 */
 #define ALOHA_NVREG 32u
 
 typedef struct aloha_vp aloha_vp;
@@ -73,6 +75,8 @@ typedef struct {
   uint32_t max_log_n;     /* largest ring size the register file is sized for (10..16)       */
   uint32_t flags;         /* ALOHA_FLAG_*                                                    */
   void *stream;           /* hipStream_t to enqueue on, or NULL for a private stream         */
+  uint32_t iram_depth;    /* instruction ROM words: 0 = ALOHA_IRAM_DEPTH (4096, inst_rom.v:32-35), up to ALOHA_IRAM_DEPTH_MAX (ABI 3) */
+  uint32_t reserved;
 } aloha_vp_config;
 
 #define ALOHA_FLAG_NO_FUSION 1u    /* one kernel per instruction (debug / parity bisecting)  */
@@ -176,6 +180,9 @@ typedef struct {
   const uint64_t *moduli;    /* L primes                                                              */
   const uint64_t *specials;  /* K primes                                                              */
   uint64_t base_row;         /* first SPM row the handle may use                                      */
+  uint32_t rom_depth;        /* instruction ROM words the phase programs may fill: 0 = ALOHA_IRAM_DEPTH; with a handle, at most
+                                that handle's iram_depth.  A phase that does not fit is cut into several programs (by modulus).   */
+  uint32_t reserved;
 } aloha_ks_config;
 /* alpha = 1 only: aloha_ks_rotate runs the reference's own phase 1 -- iNTT, vaut in the coefficient domain, NTT
  * (keyswitch.mem:4-7,:24-27,:100-121) -- instead of the NTT-domain automorphism.  Same words, except that a zero coefficient

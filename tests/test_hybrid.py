@@ -370,8 +370,8 @@ def test_hybrid_on_gpu_matches_oracle_and_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("L,op", [(24, "multiply"), (32, "rotate")])
-def test_baseline_configs_4_and_5_at_full_size_gpu_equals_oracle_machine(L, op):
+@pytest.mark.parametrize("L,op,rom", [(24, "multiply", 4096), (32, "rotate", 4096), (32, "rotate", 16384)])
+def test_baseline_configs_4_and_5_at_full_size_gpu_equals_oracle_machine(L, op, rom):
     """BASELINE config 4 (HMult + relinearisation, N = 2^16, 24 limbs) and config 5 (rotate + key-switch, 32 limbs)
     at their full sizes, hybrid alpha = 4, K = 4: every owned output word of the GPU == the oracle's ISA machine
     running the same programs (the oracle needs a few seconds per key-switch at this size)."""
@@ -395,9 +395,12 @@ def test_baseline_configs_4_and_5_at_full_size_gpu_equals_oracle_machine(L, op):
             hs.rotate(k)
         return hs.read_out()
 
-    exp = run(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows))
-    with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16) as vp:
+    # rom = 4096: the reference's instruction ROM -- the mid phase of L = 32 is then two programs (cut by modulus);
+    # rom = 16384: engine and oracle machine created with a deeper ROM, the whole phase is one program (one fused launch pair)
+    exp = run(oracle.OracleVP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, iram_depth=rom))
+    with avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows, max_log_n=16, iram_depth=rom) as vp:
         got = run(vp)
+        assert vp.config()["iram_depth"] == rom
     assert np.array_equal(got, exp)
 
 

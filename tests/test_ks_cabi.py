@@ -73,6 +73,25 @@ class _RomOnly:
         return 0
 
 
+def test_a_deeper_rom_holds_a_whole_phase():
+    """The reference's instruction ROM has 4096 words (vp_defines.vh:31); the mid phase of a key-switch at L = 32 (hybrid
+    alpha = 4) needs ~6700.  With the default depth it is cut into two programs by modulus; a plan for a handle with a
+    deeper ROM (aloha_vp_config.iram_depth) holds it in one, which the engine then runs as one fused launch pair."""
+    mods, specials = _setup(1 << 16, 32, 4)
+    with ks.KeySwitch(None, 16, mods, specials, 4) as k4, ks.KeySwitch(None, 16, mods, specials, 4, rom_depth=16384) as k16:
+        two = [k4.program("mid", i) for i in range(3)]
+        one = [k16.program("mid", i) for i in range(2)]
+        assert [len(w) > 0 for w in two] == [True, True, False] and all(len(w) <= 4096 for w in two)
+        assert len(one[0]) > 4096 and len(one[1]) == 0
+        body = lambda w: [tuple(r) for r in w[1:-1]]             # without vsetvl / break
+        assert body(two[0]) + body(two[1]) != body(one[0])       # (not a plain concatenation: each program holds whole chains ...)
+        assert sorted(body(two[0]) + body(two[1])) == sorted(body(one[0]))     # ... of the same instructions
+    with pytest.raises(avp.AlohaError):
+        ks.KeySwitch(None, 16, mods, specials, 4, rom_depth=1000)
+    with pytest.raises(avp.AlohaError):
+        ks.KeySwitch(None, 16, mods, specials, 4, rom_depth=1 << 20)
+
+
 def test_c_host_rejects_bad_configs():
     mods, specials = _setup(1024, 3, 1)
     for kw in (dict(alpha=0), dict(world=0), dict(rank=2, world=2), dict(batch=0)):

@@ -44,6 +44,7 @@ def main() -> int:
     ap.add_argument("--c-host", action="store_true",
                     help="run the key-switch through the C host (aloha_ks_*: programs generated in C++, ncclAllGather issued by the "
                          "library on its own communicator; torch.distributed only carries the 128-byte ncclUniqueId and the timing reduce)")
+    ap.add_argument("--rom", type=int, default=4096, help="instruction ROM words of the engine (4096 = the reference's; deeper holds a whole phase at L = 32)")
     ap.add_argument("--stub-world", type=int, default=0,
                     help="time rank 0's share of a W-rank layout on this one GPU with the exchanges skipped (results meaningless)")
     args = ap.parse_args()
@@ -120,7 +121,7 @@ def main() -> int:
     assert args.op != "hoisted" or args.alpha > 0
     lo = layout(world, rank)
     vp = avp.VP(spm_rows=lo.spm_rows_needed, ksk_rows=max(1, nkeys * lo.ksk_limbs * lo.rows), max_log_n=logn, device=local,
-                stream=stream.cuda_stream)
+                stream=stream.cuda_stream, iram_depth=args.rom)
     ks = build(vp, world, rank, ex)
     load(ks, lo)
     k = pow(3, 5, 2 * n)

@@ -19,6 +19,7 @@ run() {   # name, reps, args...
 }
 run hmult_L24_a4 10 --L 24 --alpha 4 --op multiply
 run rotate_L32_a4 10 --L 32 --alpha 4 --op rotate
+run rotate_L32_a4_rom16k 10 --L 32 --alpha 4 --op rotate --rom 16384
 run hmult_L24_a4_w8_rank0 10 --L 24 --alpha 4 --op multiply --stub-world 8
 tail -n 12 $O/hmult_L24_a4_timeline.txt
 cat $O/hmult_L24_a4.json
