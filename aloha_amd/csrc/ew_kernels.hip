@@ -244,6 +244,28 @@ __global__ __launch_bounds__(256) void dot_batch_kernel(const DotArgs *__restric
   }
 }
 
+// tensor product of two ciphertexts, one job per modulus (TensorJob): every input is read once
+__global__ __launch_bounds__(256) void tensor_batch_kernel(const TensorJob *__restrict__ jobs, uint32_t n2) {
+  const TensorJob *g = &jobs[blockIdx.y];                     // wave-uniform
+  const u64 q = g->m.q, mu = g->m.mu;
+  const u64x2 *A0 = reinterpret_cast<const u64x2 *>(g->a0), *A1 = reinterpret_cast<const u64x2 *>(g->a1);
+  const u64x2 *B0 = reinterpret_cast<const u64x2 *>(g->b0), *B1 = reinterpret_cast<const u64x2 *>(g->b1);
+  u64x2 *D0 = reinterpret_cast<u64x2 *>(g->d0), *D1 = reinterpret_cast<u64x2 *>(g->d1), *D2 = reinterpret_cast<u64x2 *>(g->d2);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+    u64x2 a0 = A0[i], a1 = A1[i], b0 = B0[i], b1 = B1[i];
+    a0.x = csub(a0.x, q); a0.y = csub(a0.y, q); a1.x = csub(a1.x, q); a1.y = csub(a1.y, q);   // every ALU input passes one conditional subtraction (modalu.sv:44-46)
+    b0.x = csub(b0.x, q); b0.y = csub(b0.y, q); b1.x = csub(b1.x, q); b1.y = csub(b1.y, q);
+    u64x2 r;
+    r.x = mulmod_barrett(a0.x, b0.x, q, mu); r.y = mulmod_barrett(a0.y, b0.y, q, mu);
+    D0[i] = r;
+    r.x = addmod(mulmod_barrett(a0.x, b1.x, q, mu), mulmod_barrett(a1.x, b0.x, q, mu), q);
+    r.y = addmod(mulmod_barrett(a0.y, b1.y, q, mu), mulmod_barrett(a1.y, b0.y, q, mu), q);
+    D1[i] = r;
+    r.x = mulmod_barrett(a1.x, b1.x, q, mu); r.y = mulmod_barrett(a1.y, b1.y, q, mu);
+    D2[i] = r;
+  }
+}
+
 // exact-quotient Shoup product with a wave-uniform constant, on the pinned multiplier forms: [0, 2q) for ANY a
 __device__ __forceinline__ u64 shoup_2q_u(u64 a, u64 s, u64 sp, u64 nq) {
   return mullo2_acc<true>(a, s, shoup_qhat_exact<true>(a, sp), nq);
@@ -420,6 +442,16 @@ hipError_t dot_batch(hipStream_t st, const DotArgs *d_jobs, uint32_t njobs, uint
   while (gx > 16 && (uint64_t)gx * njobs > 8192) gx /= 2;    // plenty of workgroups already: longer grid-stride loops instead
   for (uint32_t off = 0; off < njobs; off += kMaxGridY)
     hipLaunchKernelGGL(dot_batch_kernel, dim3(gx, std::min(kMaxGridY, njobs - off)), dim3(256), 0, st, d_jobs + off, n2);
+  return hipGetLastError();
+}
+
+hipError_t tensor_batch(hipStream_t st, const TensorJob *d_jobs, uint32_t njobs, uint32_t n) {
+  if (!njobs) return hipSuccess;
+  const uint32_t n2 = n / 2;
+  uint32_t gx = grid_for(n2);
+  while (gx > 16 && (uint64_t)gx * njobs > 8192) gx /= 2;
+  for (uint32_t off = 0; off < njobs; off += kMaxGridY)
+    hipLaunchKernelGGL(tensor_batch_kernel, dim3(gx, std::min(kMaxGridY, njobs - off)), dim3(256), 0, st, d_jobs + off, n2);
   return hipGetLastError();
 }
 

@@ -55,6 +55,16 @@ hipError_t ew_batch(hipStream_t st, const EwJob *d_jobs, uint32_t njobs, uint32_
 // two_pass: every job is an automorphism (no roll) -> two coalesced LDS passes for N >= 2^12 (ew_kernels.hip)
 hipError_t aut_batch(hipStream_t st, const AutJob *d_jobs, uint32_t njobs, unsigned logn, bool two_pass);
 
+// The tensor product of two ciphertexts under one modulus (the first step of a homomorphic product; no reference
+// program ships): d0 = a0 .* b0, d1 = a0 .* b1 + a1 .* b0, d2 = a1 .* b1 -- as instructions two
+// vfqmul.vv with stores and a two-term sum: 11 limb passes; here one pass over the four inputs, 7.
+struct TensorJob {
+  const u64 *a0, *a1, *b0, *b1;
+  u64 *d0, *d1, *d2;
+  ModCtx m;
+};
+hipError_t tensor_batch(hipStream_t st, const TensorJob *d_jobs, uint32_t njobs, uint32_t n);
+
 // d = init + sum_t a[t] .* (b[t] | s[t])  (mod q), up to kDotTerms terms per launch: the key-switch
 // inner product (keyswitch.mem:46-79) as ONE pass over its operands.
 constexpr int kDotTerms = 64;

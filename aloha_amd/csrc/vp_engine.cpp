@@ -1243,6 +1243,81 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     for (size_t i = 0; i < D.size(); i++) if (!d_fused[i]) rest.push_back(D[i]);
     return launch_dots(rest, lg);
   };
+  // Element-wise products followed by sums: the tensor product of two ciphertexts is, per modulus, two `vfqmul.vv; vse`
+  // (d0 = a0 b0, d2 = a1 b1) and a two-term sum (d1 = a0 b1 + a1 b0) over the same four limbs.  The batch of products is
+  // held when sums follow; at the flush every (d0, d2, d1) triple over one quadruple of operands leaves as ONE job of
+  // tensor_batch (each input read once: 7 limb passes instead of 11), the rest as before, in stage order.
+  std::vector<aloha::k::EwJob> held_ew;
+  auto launch_tensor = [&]() -> aloha_status {
+    std::vector<aloha::k::EwJob> E;
+    std::vector<aloha::k::DotArgs> D;
+    E.swap(held_ew);
+    if (pend_kind == PK_DOT) D.swap(dot_batch);
+    const unsigned lg = batch_logn;
+    const uint32_t nn = 1u << lg;
+    std::vector<aloha::k::TensorJob> T;
+    std::vector<char> e_used(E.size(), 0), d_used(D.size(), 0);
+    std::map<std::pair<const u64 *, const u64 *>, size_t> mul_of;   // (a, b) of a product -> its job
+    for (size_t i = 0; i < E.size(); i++)
+      if (E[i].op == aloha::k::EW_MUL_VV) mul_of[{E[i].a, E[i].b}] = i;
+    auto e_writes = [&](const u64 *p_) { for (const auto &e : E) if (overlap(p_, e.d, nn)) return true; return false; };
+    auto e_touches = [&](const u64 *p_) {
+      for (const auto &e : E) if (overlap(p_, e.d, nn) || overlap(p_, e.a, nn) || overlap(p_, e.b, nn)) return true;
+      return false;
+    };
+    for (size_t j = 0; j < D.size(); j++) {
+      const auto &g = D[j];
+      if (g.init || g.nterms != 2 || !g.a[0] || !g.b[0] || !g.a[1] || !g.b[1]) continue;
+      // g = x0 .* y1 + x1 .* y0 with products (x0, y0) and (x1, y1) in the held batch (either operand order)
+      size_t i0 = 0, i1 = 0;
+      bool found = false;
+      for (int sw = 0; sw < 4 && !found; sw++) {
+        const u64 *x0 = (sw & 1) ? g.b[0] : g.a[0], *y1 = (sw & 1) ? g.a[0] : g.b[0];
+        const u64 *x1 = (sw & 2) ? g.b[1] : g.a[1], *y0 = (sw & 2) ? g.a[1] : g.b[1];
+        for (int ord = 0; ord < 4 && !found; ord++) {
+          auto f0 = mul_of.find((ord & 1) ? std::make_pair(y0, x0) : std::make_pair(x0, y0));
+          auto f1 = mul_of.find((ord & 2) ? std::make_pair(y1, x1) : std::make_pair(x1, y1));
+          if (f0 == mul_of.end() || f1 == mul_of.end() || f0->second == f1->second || e_used[f0->second] || e_used[f1->second]) continue;
+          const auto &e0 = E[f0->second], &e1 = E[f1->second];
+          if (e0.m.q != g.m.q || e1.m.q != g.m.q) continue;
+          // fusing reads the four operands while d0, d2 and d1 are written: none of the batch's outputs may be an operand
+          // of the sum, and the sum's output may not touch anything the batch reads or writes
+          if (e_writes(x0) || e_writes(x1) || e_writes(y0) || e_writes(y1) || e_touches(g.d)) continue;
+          aloha::k::TensorJob t{};
+          t.a0 = x0; t.a1 = x1; t.b0 = y0; t.b1 = y1; t.d0 = e0.d; t.d2 = e1.d; t.d1 = g.d; t.m = g.m;
+          T.push_back(t);
+          e_used[f0->second] = e_used[f1->second] = 1; d_used[j] = 1;
+          i0 = f0->second; i1 = f1->second; found = true;
+        }
+      }
+      (void)i0; (void)i1;
+    }
+    aloha_status s = ALOHA_OK;
+    std::vector<aloha::k::EwJob> e_rest;
+    for (size_t i = 0; i < E.size(); i++) if (!e_used[i]) e_rest.push_back(E[i]);
+    if (!e_rest.empty()) {
+      const void *dj = nullptr;
+      s = device_blob(vp, e_rest.data(), e_rest.size() * sizeof(e_rest[0]), &dj);
+      if (s) return s;
+      const uint32_t nj = (uint32_t)e_rest.size();
+      const hipError_t e = issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::ew_batch(st, (const aloha::k::EwJob *)dj, nj, nn); });
+      if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "ew_batch: %s", hipGetErrorString(e));
+    }
+    if (!T.empty()) {
+      const void *dj = nullptr;
+      s = device_blob(vp, T.data(), T.size() * sizeof(T[0]), &dj);
+      if (s) return s;
+      const uint32_t nj = (uint32_t)T.size();
+      const hipError_t e = issue(vp, [=]() -> hipError_t {
+        vp->stats.kernel_launches++; vp->stats.ks_fused_launches++;
+        return aloha::k::tensor_batch(st, (const aloha::k::TensorJob *)dj, nj, nn);
+      });
+      if (e != hipSuccess) return fail(vp, ALOHA_ERR_DEVICE, "tensor_batch: %s", hipGetErrorString(e));
+    }
+    std::vector<aloha::k::DotArgs> d_rest;
+    for (size_t j = 0; j < D.size(); j++) if (!d_used[j]) d_rest.push_back(D[j]);
+    return launch_dots(d_rest, lg);
+  };
   auto reset_pending = [&]() {
     pend_rw.clear();
     box_r_lo = box_r_hi = box_w_lo = box_w_hi = nullptr;
@@ -1252,7 +1327,8 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   const bool stage_ok = fuse && !(vp->flags & ALOHA_FLAG_RADIX2_ONLY) && !getenv("ALOHA_NO_STAGES");   // (the variable: A/B timing switch)
   auto flush = [&]() -> aloha_status {
     aloha_status s = ALOHA_OK;
-    if (!held_sums.empty() || !held_ntt.empty()) s = launch_staged();       // (takes the pending batch with it when that is the next stage)
+    if (!held_ew.empty()) s = launch_tensor();                              // (takes the pending sums with it)
+    else if (!held_sums.empty() || !held_ntt.empty()) s = launch_staged();  // (takes the pending batch with it when that is the next stage)
     if (s) {
     } else if (pend_kind == PK_NTT && !batch.empty()) {
       s = run_transforms(vp, batch, batch_logn, batch_inv);
@@ -1626,7 +1702,7 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           auto joinable = [&]() { return can_join(PK_NTT, logn, src, nullptr, z, n) && (batch.empty() || batch_inv == inv); };
           // forward transforms at N = 2^16 behind a batch of sums: the sums are held, not launched (staged batches, above)
           if (stage_ok && !inv && logn == 16 && pend_kind == PK_DOT && batch_logn == 16 && !dot_batch.empty() && held_sums.empty() &&
-              held_ntt.empty()) {
+              held_ntt.empty() && held_ew.empty()) {
             held_sums.swap(dot_batch);
             reset_pending();
           }
@@ -1700,6 +1776,11 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
                 return true;
               };
               // a sum behind a batch of forward transforms at N = 2^16: the transforms are held (staged batches, above)
+              // sums behind a batch of element-wise products: the products are held (tensor product, above)
+              if (stage_ok && pend_kind == PK_EW && batch_logn == logn && !ew_batch.empty() && held_ew.empty() && held_sums.empty() && held_ntt.empty()) {
+                held_ew.swap(ew_batch);
+                reset_pending();
+              }
               if (stage_ok && logn == 16 && pend_kind == PK_NTT && !batch_inv && batch_logn == 16 && !batch.empty() && held_ntt.empty()) {
                 held_ntt.swap(batch);
                 reset_pending();

@@ -104,6 +104,10 @@ def _dot(xs, ks, dst):
     return out + [f"vse v8, abs+{dst * 8 * N:#x}"]
 
 
+def _ew(a, b, dst):
+    return [f"vle v0, abs+{a * 8 * N:#x}", f"vle v1, abs+{b * 8 * N:#x}", "vfqmul.vv v2, v0, v1", f"vse v2, abs+{dst * 8 * N:#x}"]
+
+
 def test_chains_the_kernels_do_not_cover_fall_back_exactly():
     """Hand-written sum -> transform -> sum chains with the irregularities the matcher must refuse or handle: a sum whose
     operand another transform of the batch overwrites, an out-of-place transform of a sum, a later load of a transformed
@@ -132,6 +136,13 @@ def test_chains_the_kernels_do_not_cover_fall_back_exactly():
         "two_moduli": setq(q) + _sum(q, [0, 1], [3, 5], 8) + setq(q1) + _sum(q1, [0, 1], [3, 5], 9) + setq(q) + _ntt(8) + setq(q1) + _ntt(9) +
                       setq(q) + _dot([8, 4], [5, 6], 16) + _dot([8, 4], [6, 7], 17) + setq(q1) + _dot([9, 4], [5, 6], 18) + _dot([9, 4], [6, 7], 19),
     }
+    progs.update({
+        # 6: the tensor product of two ciphertexts (products held, the cross sum matched to them), operands in every order
+        "tensor": setq(q) + _ew(0, 1, 8) + _ew(2, 3, 9) + _ew(4, 5, 12) + _ew(7, 6, 13) + _ew(0, 5, 20) +
+                  _dot([0, 2], [3, 1], 16) + _dot([5, 6], [7, 4], 17) + _dot([0, 1], [2, 3], 18),
+        # 7: a product in place on an operand of the sum, a sum that overwrites a product's operand: no fusion, same results
+        "tensor_hazards": setq(q) + _ew(0, 1, 0) + _ew(2, 3, 9) + _dot([0, 2], [3, 1], 16) + _ew(4, 5, 12) + _ew(6, 7, 13) + _dot([4, 6], [7, 5], 5),
+    })
     for name, lines in progs.items():
         words = _program(lines)
         res = {}
