@@ -24,17 +24,15 @@ namespace k {
 
 namespace {
 
-// QUAD: the variant for grids that do not fill the chip (all operands of a sum in flight at once, 3 waves per SIMD)
-template <bool QUAD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QUAD ? 3 : 4, QUAD ? 3 : 4))) void ntt_col_pro_kernel(
-    const LimbJob *__restrict__ jobs, const PrimeDev *__restrict__ primes, uint32_t count, const SumSrc *__restrict__ sums) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_col_pro_kernel(const LimbJob *__restrict__ jobs, const PrimeDev *__restrict__ primes, uint32_t count,
+                                                          const SumSrc *__restrict__ sums) {
   __shared__ u64 sdata[LINES * PITCH];
   // XCD-affine tile order, as in ntt_col_kernel
   const uint32_t b = blockIdx.x, full = (count >> 3) << 7;
   const uint32_t limb = b < full ? ((b >> 7) << 3) + (b & 7) : (b >> 4);
   const uint32_t cg = b < full ? (b >> 3) & 15 : (b & 15);
   const LimbJob jb = jobs[limb];
-  col_tile_fwd<true, false, true, QUAD>(sdata, jb, &primes[jb.prime], cg, threadIdx.x, sums);
+  col_tile_fwd<true, false, true>(sdata, jb, &primes[jb.prime], cg, threadIdx.x, sums);
 }
 
 // Row pass (second pass of a forward transform) whose lines may end in an epilogue.  A line with an epilogue is not
@@ -359,8 +357,7 @@ __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(R == 2 ?
 hipError_t ntt_fwd16_cols(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count, const SumSrc *d_sums,
                           uint64_t *launches) {
   if (!count) return hipSuccess;
-  if (count * 16 <= 768) hipLaunchKernelGGL(ntt_col_pro_kernel<true>, dim3(count * 16), dim3(256), 0, st, d_jobs, d_primes, count, d_sums);
-  else hipLaunchKernelGGL(ntt_col_pro_kernel<false>, dim3(count * 16), dim3(256), 0, st, d_jobs, d_primes, count, d_sums);
+  hipLaunchKernelGGL(ntt_col_pro_kernel, dim3(count * 16), dim3(256), 0, st, d_jobs, d_primes, count, d_sums);
   if (launches) ++*launches;
   return hipGetLastError();
 }

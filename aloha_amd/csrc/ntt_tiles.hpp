@@ -52,37 +52,10 @@ __device__ __forceinline__ void sum_pair(u64 (&v)[NV], const SumSrc *__restrict_
     for (int i = 0; i < NV; i++) v[i] += APPROX ? mul_shoup_4q<true>(x1[i], s1, sp1, nq) : shoup_2q_uni(x1[i], s1, sp1, nq);
   }
 }
-// ... and all of <= 4 operands at once where the grid is small enough that a workgroup's latency, not the chip's
-// throughput, is the kernel's time (QUAD: 3 waves per SIMD, one wait for the loads instead of two)
 template <int NV, class ADDR>
-__device__ __forceinline__ void sum_quad(u64 (&v)[NV], const SumSrc *__restrict__ ss, int T, const ADDR &addr, u64 nq) {
-  u64 x[4][NV];
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    cgptr_t a = (cgptr_t)ss->a[t < T ? t : 0];
-    if (t < T) {
-#pragma unroll
-      for (int i = 0; i < NV; i++) x[t][i] = a[addr(i)];
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    if (t < T) {
-      const u64 s = ss->s[t], sp = ss->sp[t];
-#pragma unroll
-      for (int i = 0; i < NV; i++) {
-        const u64 p = mul_shoup_4q<true>(x[t][i], s, sp, nq);
-        v[i] = t ? v[i] + p : p;
-      }
-    }
-  }
-}
-template <bool QUAD, int NV, class ADDR>
 __device__ __forceinline__ void sum_prologue(u64 (&v)[NV], const SumSrc *__restrict__ ss, const ADDR &addr, u64 q, u64 nq, u32 kc) {
   const int T = ss->nterms;                                      // (wave-uniform)
-  if (QUAD && T <= 4) {
-    sum_quad(v, ss, T, addr, nq);
-  } else if (T <= 4) {
+  if (T <= 4) {
     sum_pair<true>(v, ss, 0, T > 1, true, addr, nq);
     if (T > 2) sum_pair<true>(v, ss, 2, T > 3, false, addr, nq);
   } else {
@@ -99,7 +72,7 @@ __device__ __forceinline__ void sum_prologue(u64 (&v)[NV], const SumSrc *__restr
 // Both mappings touch memory in 128-byte row segments: forward loads in A and stores from B,
 // inverse loads in B and stores from A.  One LDS exchange and one barrier per tile.  The
 // stage 0..3 twiddles are the same for every thread (scalar loads -> SGPR operands).
-template <bool FIRST, bool LAST, bool PRO, bool QUAD = false>
+template <bool FIRST, bool LAST, bool PRO>
 __device__ __forceinline__ void col_tile_fwd(u64 *sdata, const LimbJob &jb, const PrimeDev *pr, uint32_t cg, int tid,
                                              const SumSrc *__restrict__ sums) {
   const uint32_t col = tid & 15, slow = tid >> 4;
@@ -112,7 +85,7 @@ __device__ __forceinline__ void col_tile_fwd(u64 *sdata, const LimbJob &jb, cons
   constexpr int BIN = FIRST ? FWD_IN : FWD_MID;
   if (PRO && jb.pro) {                                                    // (workgroup-uniform)
     const uint32_t base = cg * 16 + offA;
-    sum_prologue<QUAD, 16>(v, sums + (jb.pro - 1), [&](int kk) { return base + ((uint32_t)(16 * kk) << 8); }, q, nq, (u32)pr->m.kc);
+    sum_prologue<16>(v, sums + (jb.pro - 1), [&](int kk) { return base + ((uint32_t)(16 * kk) << 8); }, q, nq, (u32)pr->m.kc);
   } else {
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) v[kk] = ld_stream(&(src + ((size_t)(16 * kk) << 8))[offA]);
