@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(LIBDIR, "libaloha_vp.so")
-SOURCES = ["vp_engine.cpp", "keyswitch_host.cpp", "numtheory.cpp", "ew_kernels.hip", "ntt_tile.hip", "ntt_ks.hip", "ntt_single.hip", "encode_kernels.hip"]
+SOURCES = ["vp_engine.cpp", "keyswitch_host.cpp", "numtheory.cpp", "ew_kernels.hip", "ntt_tile.hip", "ntt_ks.hip", "ntt_single.hip", "ntt_product.hip", "encode_kernels.hip"]
 HEADERS = ["kernels.hpp", "modarith.hpp", "ntt_device.hpp", "ntt_tiles.hpp", "numtheory.hpp", os.path.join("..", "..", "include", "aloha_vp.h")]
 # Variant builds (measured-and-rejected experiments, ablations): the two-pass tile kernels with every knob and
 # the single-launch transforms replace the default tile file, and -DALOHA_EXPERIMENTS enables their switches in the engine

@@ -230,6 +230,20 @@ hipError_t ntt_fused_fwd(hipStream_t st, const LimbJob *d_jobs, const LimbJob *d
 hipError_t ntt_single_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
                             unsigned logn, bool inverse, uint64_t *launches, bool scaled = false);
 
+// ---- polynomial product at N = 2^14 as one launch (ntt_product.hip) ----------------------------------------------------
+// d = iNTT(NTT(a) .* NTT(b)) under the job's modulus: `vle; vntt; vle; vntt; vfqmul.vv; vintt; vse` (BASELINE config 3).
+struct ProdJob {
+  const u64 *a, *b;
+  u64 *d;
+  uint32_t prime, pad;
+};
+constexpr uint32_t kProdMaxLimbs = 64;           // limbs per launch
+size_t poly_product_ctl_words();                 // u32 words of control memory (arrival counters in two banks + a status word), zeroed once
+// d_work: 2 * count * 2^14 words of scratch (the transforms' intermediates); gen: the handle's count of product launches
+// (selects the counter bank); the last word of d_ctl is sticky: non-zero after a launch gave up on a bounded wait
+hipError_t poly_product_batch(hipStream_t st, const ProdJob *d_jobs, const PrimeDev *d_primes, uint32_t count, u64 *d_work, uint32_t *d_ctl,
+                              uint32_t gen, uint64_t *launches);
+
 // ---- measurement helpers (ew_kernels.hip) ---------------------------------------------------------------
 // limb i of `count` limbs of n words at base + i*n: the first n accepted candidates (top 60 bits, < moduli[i]) of the
 // splitmix64 stream seeded with seed_base + first_index + i

@@ -123,6 +123,12 @@ struct aloha_vp {
   std::map<unsigned, EncTab> enc_tables;
   void *d_enc_in = nullptr, *d_enc_work = nullptr;
   size_t enc_in_bytes = 0, enc_work_bytes = 0;
+  // polynomial products at N = 2^14 as one launch (ntt_product.hip): scratch for the transforms' intermediates, the arrival
+  // counters (two banks, used by alternate launches) with a sticky status word behind them; allocated at the first product
+  u64 *d_prod_work = nullptr;
+  uint32_t *d_prod_ctl = nullptr;
+  uint32_t prod_gen = 0;                             // product launches so far
+  bool prod_unchecked = false;                       // a product launch ran since the status word was last read
   // Launch lists of whole program runs, replayed when the same program segment is run again with the same CSRs
   // and the same architectural state on entry: the sequencer is a pure function of those (no data-dependent
   // control flow in the ISA), so a repeated phase of a key-switch costs its kernel launches and nothing else.
@@ -321,11 +327,24 @@ aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
 
 // After a synchronisation: did a fused transform give up on one of its bounded waits?  (It cannot in a correct
 // schedule -- see ntt_fused_fwd_kernel -- but a wait that can be bounded is, and the bound is reported.)
+aloha_status check_product(aloha_vp *vp) {
+  if (!vp->prod_unchecked) return ALOHA_OK;
+  uint32_t st = 0;
+  uint32_t *word = vp->d_prod_ctl + aloha::k::poly_product_ctl_words() - 16;
+  HIPCK(vp, hipMemcpyAsync(&st, word, 4, hipMemcpyDeviceToHost, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  vp->prod_unchecked = false;
+  if (!st) return ALOHA_OK;
+  HIPCK(vp, hipMemsetAsync(vp->d_prod_ctl, 0, aloha::k::poly_product_ctl_words() * 4, vp->stream));
+  vp->prod_gen = 0;
+  return fail(vp, ALOHA_ERR_DEVICE, "a fused polynomial product gave up on a bounded wait (%u waits): its output is incomplete", st);
+}
+
 aloha_status check_fused(aloha_vp *vp) {
 #ifndef ALOHA_EXPERIMENTS
-  (void)vp;
-  return ALOHA_OK;
+  return check_product(vp);
 #else
+  { aloha_status sp = check_product(vp); if (sp) return sp; }
   if (!vp->fused_unchecked) return ALOHA_OK;
   uint32_t st = 0;
   HIPCK(vp, hipMemcpyAsync(&st, vp->d_fused_status, 4, hipMemcpyDeviceToHost, vp->stream));
@@ -599,6 +618,8 @@ void aloha_vp_destroy(aloha_vp *vp) {
 #endif
   if (vp->d_enc_in) (void)hipFree(vp->d_enc_in);
   if (vp->d_enc_work) (void)hipFree(vp->d_enc_work);
+  if (vp->d_prod_work) (void)hipFree(vp->d_prod_work);
+  if (vp->d_prod_ctl) (void)hipFree(vp->d_prod_ctl);
   if (vp->own_stream && vp->stream) (void)hipStreamDestroy(vp->stream);
   delete vp;
 }
@@ -674,6 +695,17 @@ aloha_status aloha_vp_load_isram_hex(aloha_vp *vp, uint32_t base_pc, const char 
   }
   return aloha_vp_load_isram(vp, base_pc, words.data(), (uint32_t)(words.size() / 3));
 }
+
+#ifdef ALOHA_EXPERIMENTS
+// variant builds with -DALOHA_PROD_TRACE: the clock stamps the product kernel left behind its scratch (tests/perf/product_trace.py)
+aloha_status aloha_vp_debug_product_trace(aloha_vp *vp, void *dst, uint64_t bytes) {
+  if (!vp || !dst || !vp->d_prod_work || bytes > (1u << 20)) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
+  HIPCK(vp, hipMemcpyAsync(dst, vp->d_prod_work + ((size_t)aloha::k::kProdMaxLimbs * 2 << 14), bytes, hipMemcpyDeviceToHost, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  return ALOHA_OK;
+}
+#endif
 
 aloha_status aloha_vp_sync(aloha_vp *vp) {
   if (!vp) return ALOHA_ERR_ARG;
@@ -870,8 +902,9 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   const uint64_t epoch0 = vp->epoch;
   const u64 *alias[ALOHA_NVREG] = {nullptr};                // non-null: the register's value is memory at this address
   // Pending batch: deferred memory-to-memory jobs of ONE kind, launched together by flush().
-  enum { PK_NONE, PK_NTT, PK_AUT, PK_EW, PK_DOT } pend_kind = PK_NONE;
+  enum { PK_NONE, PK_NTT, PK_AUT, PK_EW, PK_DOT, PK_PROD } pend_kind = PK_NONE;
   std::vector<LimbJob> batch;                               // PK_NTT
+  std::vector<aloha::k::ProdJob> prod_batch;                // PK_PROD: whole products iNTT(NTT(a) .* NTT(b)) at N = 2^14
   std::vector<aloha::k::AutJob> aut_batch;                  // PK_AUT
   std::vector<aloha::k::DotArgs> dot_batch;                 // PK_DOT: lazy dot products stored straight to memory
   const u64 *dot_w_lo = nullptr, *dot_w_hi = nullptr, *dot_a_lo = nullptr, *dot_a_hi = nullptr, *dot_b_lo = nullptr,
@@ -1361,7 +1394,34 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     else if (pend_kind == PK_DOT && !dot_batch.empty()) {
       s = launch_dots(dot_batch, batch_logn);
     }
-    batch.clear(); aut_batch.clear(); ew_batch.clear(); dot_batch.clear(); pend_rw.clear();
+    else if (pend_kind == PK_PROD && !prod_batch.empty()) {
+      if (!vp->d_prod_ctl) {                                   // first product of this handle: scratch and counters
+        const size_t cw = aloha::k::poly_product_ctl_words() * 4, ww = ((size_t)aloha::k::kProdMaxLimbs * 2 * 8 << 14) + (1u << 20);   // (+ 1 MiB: clock stamps of trace builds)
+        if (hipMalloc(&vp->d_prod_work, ww) != hipSuccess || hipMalloc(&vp->d_prod_ctl, cw) != hipSuccess ||
+            hipMemsetAsync(vp->d_prod_ctl, 0, cw, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+          if (vp->d_prod_work) (void)hipFree(vp->d_prod_work);
+          if (vp->d_prod_ctl) (void)hipFree(vp->d_prod_ctl);
+          vp->d_prod_work = nullptr; vp->d_prod_ctl = nullptr;
+          s = fail(vp, ALOHA_ERR_DEVICE, "polynomial product: scratch allocation failed");
+        }
+      }
+      for (size_t j0 = 0; !s && j0 < prod_batch.size(); j0 += aloha::k::kProdMaxLimbs) {
+        const uint32_t nj = (uint32_t)std::min<size_t>(aloha::k::kProdMaxLimbs, prod_batch.size() - j0);
+        const void *dj = nullptr;
+        s = device_blob(vp, prod_batch.data() + j0, nj * sizeof(prod_batch[0]), &dj);
+        if (s) break;
+        const hipError_t e = issue(vp, [=]() -> hipError_t {
+          uint64_t launches = 0;
+          const hipError_t e2 = aloha::k::poly_product_batch(st, (const aloha::k::ProdJob *)dj, vp->d_primes, nj, vp->d_prod_work, vp->d_prod_ctl,
+                                                             vp->prod_gen++, &launches);
+          vp->stats.kernel_launches += launches;
+          vp->prod_unchecked = true;
+          return e2;
+        });
+        if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "poly_product_batch: %s", hipGetErrorString(e));
+      }
+    }
+    batch.clear(); aut_batch.clear(); ew_batch.clear(); dot_batch.clear(); prod_batch.clear(); pend_rw.clear();
     box_r_lo = box_r_hi = box_w_lo = box_w_hi = nullptr;
     dot_w_lo = dot_w_hi = dot_a_lo = dot_a_hi = dot_b_lo = dot_b_hi = nullptr;
     pend_kind = PK_NONE;
@@ -1691,6 +1751,63 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
                 scaled.addc = addc;
               }
             }
+          }
+        }
+        // `vntt t1, vA ; vntt t2, vB ; vfqmul.vv t3, t1, t2 ; vintt t4, t3 ; vse t4, Z` over memory operands vA, vB (loads may
+        // stand anywhere among them), every temporary dead afterwards, N = 2^14: ONE job of the product kernel
+        // (ntt_product.hip; BASELINE config 3) instead of two transforms, a product, an inverse transform and their stores.
+        if (!z && !inv && fuse && logn == 14 && alias[vs1] && !(vp->flags & (ALOHA_FLAG_RADIX2_ONLY | ALOHA_FLAG_NTT_TWO_PASS)) &&
+            !getenv("ALOHA_NO_PRODUCT")) {                         // (the variable: A/B timing switch)
+          enum { S_NONE, S_MEM, S_NTT, S_PROD, S_RES };
+          struct Sym { int kind; const u64 *a, *b; };
+          Sym sym[ALOHA_NVREG];
+          for (unsigned r = 0; r < ALOHA_NVREG; r++) sym[r] = Sym{(alias[r] && lazy[r].empty()) ? S_MEM : S_NONE, alias[r], nullptr};
+          std::vector<std::pair<unsigned, u64 *>> loads;           // the window's own vle: (register, rows)
+          u64 *zz = nullptr;
+          const u64 *pa = nullptr, *pb = nullptr;
+          uint32_t end = 0;
+          bool ok = true;
+          for (uint32_t i = pc; ok && !zz && i < pc + 10 && i < vp->iram_depth; i++) {
+            const Decoded m = decode_at(vp, i);
+            switch (m.funct6) {
+              case 0x03: {
+                u64 *p = mem_rows(vp, m.imm, true, csr, n / kLanes);
+                if (!p) ok = false; else { sym[m.vd] = Sym{S_MEM, p, nullptr}; loads.emplace_back(m.vd, p); }
+                break;
+              }
+              case 0x02: if (sym[m.vs1].kind == S_MEM) sym[m.vd] = Sym{S_NTT, sym[m.vs1].a, nullptr}; else ok = false; break;
+              case 0x01:
+                if (m.funct3 == 0 && ((m.vs1 ^ m.vs2) & 1) && sym[m.vs1].kind == S_NTT && sym[m.vs2].kind == S_NTT)
+                  sym[m.vd] = Sym{S_PROD, sym[m.vs1].a, sym[m.vs2].a};
+                else ok = false;
+                break;
+              case 0x06: if (sym[m.vs1].kind == S_PROD) sym[m.vd] = Sym{S_RES, sym[m.vs1].a, sym[m.vs1].b}; else ok = false; break;
+              case 0x07:
+                if (sym[m.vs1].kind == S_RES) { zz = mem_rows(vp, m.imm, false, csr, n / kLanes); pa = sym[m.vs1].a; pb = sym[m.vs1].b; end = i; ok = zz != nullptr; }
+                else ok = false;
+                break;
+              default: ok = false;
+            }
+          }
+          ok = ok && zz;
+          for (unsigned r = 0; ok && r < ALOHA_NVREG; r++)
+            if (sym[r].kind >= S_NTT && !dead_from(vp, end + 1, r)) ok = false;
+          // the destination may BE an operand (its columns are read before they are written), not straddle one
+          if (ok && ((zz != pa && overlap(zz, pa, n)) || (zz != pb && overlap(zz, pb, n)))) ok = false;
+          if (ok) {
+            if (!can_join(PK_PROD, logn, pa, pb, zz, n)) ALOHA_RUN_CK(flush());
+            for (const auto &ld : loads) { lazy[ld.first].clear(); alias[ld.first] = ld.second; }
+            for (unsigned r = 0; r < ALOHA_NVREG; r++)
+              if (sym[r].kind >= S_NTT) { lazy[r].clear(); alias[r] = nullptr; }   // (dead: whatever they held is gone)
+            ALOHA_RUN_CK(before_mem_write(zz, n, end + 1));
+            if (!can_join(PK_PROD, logn, pa, pb, zz, n)) ALOHA_RUN_CK(flush());
+            prod_batch.push_back(aloha::k::ProdJob{pa, pb, zz, slot, 0});
+            note_rw(pa, zz, n);
+            note_rw(pb, zz, n);
+            pend_kind = PK_PROD; batch_logn = logn;
+            vp->stats.instructions += end - pc;
+            pc = end;
+            break;
           }
         }
         const u64 *src = rd(vs1);

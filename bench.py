@@ -221,22 +221,50 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
     rng = np.random.default_rng(3)
     a = np.stack([rng.integers(0, m, n, dtype=np.uint64) for m in mods])
     b = np.stack([rng.integers(0, m, n, dtype=np.uint64) for m in mods])
-    words = programs.assemble(programs.poly_mul_batched(n, mods, scratch_row=3 * L * rows))
+    # the product as the ISA writes it (mul_plain.mem:4-19's shape with the transforms added): the sequencer hands every limb's
+    # `vle; vntt; vle; vntt; vfqmul.vv; vintt; vse` to ONE kernel (csrc/ntt_product.hip); `loop_by_loop_us`: the same product
+    # written as four loops with stores in between (one batched launch per loop and pass, the form of rounds 1-2)
+    words = programs.assemble(programs.poly_mul(n, mods))
+    words_loops = programs.assemble(programs.poly_mul_batched(n, mods, scratch_row=3 * L * rows))
     with avp.VP(spm_rows=4 * L * rows, ksk_rows=1, max_log_n=14, device=device) as vp:
         o = oracle.OracleVP(spm_rows=4 * L * rows, ksk_rows=1)
         for e in (vp, o):
             e.write(SPM, 0, a.reshape(-1)); e.write(SPM, L * rows, b.reshape(-1)); e.load_isram(0, words)
+        vp.load_isram(2048, words_loops)
         run = lambda: vp.run(0, src0=0, src1=L * rows, rslt=2 * L * rows)
         assert run() == 0
         t0 = time.perf_counter(); assert o.run(0, src0=0, src1=L * rows, rslt=2 * L * rows) == 0; cpu_ms = (time.perf_counter() - t0) * 1e3
-        ok = bool(np.array_equal(vp.read(SPM, 2 * L * rows, L * n), o.read(SPM, 2 * L * rows, L * n)))
+        want = o.read(SPM, 2 * L * rows, L * n)
+        ok = bool(np.array_equal(vp.read(SPM, 2 * L * rows, L * n), want))
         l0 = vp.stats()["kernel_launches"]
         t = timeit(run, vp.sync, 100)
+        launches = (vp.stats()["kernel_launches"] - l0) / 101
+        run_loops = lambda: vp.run(2048, src0=0, src1=L * rows, rslt=2 * L * rows)
+        assert run_loops() == 0
+        ok = ok and bool(np.array_equal(vp.read(SPM, 2 * L * rows, L * n), want))
+        t_loops = timeit(run_loops, vp.sync, 100)
         by = acc.polymul_bytes(n, L)
-        out["config3_polymul_n16384_8limbs"] = {"us": t * 1e6, "launches": (vp.stats()["kernel_launches"] - l0) / 101, "algorithmic_bytes": by,
+        out["config3_polymul_n16384_8limbs"] = {"us": t * 1e6, "launches": launches, "algorithmic_bytes": by,
                                                 "fused_min_GBps": by["fused_minimum"] / t / 1e9, "frac": by["fused_minimum"] / t / 1e9 / HBM_PEAK_GBS,
-                                                "verified": ok, "cpu_port_ms": cpu_ms}
+                                                "loop_by_loop_us": t_loops * 1e6, "verified": ok, "cpu_port_ms": cpu_ms}
         o.close()
+    # ... and 64 limbs (8 such products) per run: the same kernel with the chip half full
+    Lb = 64
+    mods_b = [avp.nth_prime(logn, i % L) for i in range(Lb)]
+    with avp.VP(spm_rows=3 * Lb * rows, ksk_rows=1, max_log_n=14, device=device) as vp:
+        vp.fill_synthetic(SPM, 0, logn, mods_b + mods_b, seed_base=0xA10A + 300000)
+        vp.load_isram(0, programs.assemble(programs.poly_mul(n, mods_b)))
+        run = lambda: vp.run(0, src0=0, src1=Lb * rows, rslt=2 * Lb * rows)
+        assert run() == 0
+        x, y = vp.read(SPM, 0, n), vp.read(SPM, Lb * rows, n)
+        fx, fy = oracle.ntt(x, mods_b[0]), oracle.ntt(y, mods_b[0])
+        prod = np.array([(int(u) * int(v)) % mods_b[0] for u, v in zip(fx, fy)], dtype=np.uint64)
+        okb = bool(np.array_equal(vp.read(SPM, 2 * Lb * rows, n), oracle.intt(prod, mods_b[0])))
+        tb = timeit(run, vp.sync, 50)
+        byb = acc.polymul_bytes(n, Lb)
+        out["config3_polymul_n16384_8limbs"]["batch_of_8_products"] = {
+            "us_per_product": tb * 1e6 / 8, "limbs": Lb, "fused_min_GBps": byb["fused_minimum"] / tb / 1e9,
+            "frac": byb["fused_minimum"] / tb / 1e9 / HBM_PEAK_GBS, "verified": okb}
 
     # -- configs 4 / 5: HMult + relinearisation at L = 24, rotate + key-switch at L = 32 (N = 2^16, hybrid alpha = K = 4) -------
     def keyswitch(L, op):

@@ -85,16 +85,24 @@ def config3():
     b = np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in mods])
     with avp.VP(spm_rows=4 * L * rows, ksk_rows=1, max_log_n=14) as vp:
         vp.write(SPM, 0, a.reshape(-1)); vp.write(SPM, L * rows, b.reshape(-1))
-        vp.load_isram(0, programs.assemble(programs.poly_mul_batched(n, mods, scratch_row=3 * L * rows)))
-        run = lambda: vp.run(0, src0=0, src1=L * rows, rslt=2 * L * rows)
-        assert run() == 0
-        got = vp.read(SPM, 2 * L * rows, n)
+        # the product as the ISA writes it, limb by limb: one launch (csrc/ntt_product.hip); and written loop by loop with stores
+        # in between (the form of rounds 1-2: one batched launch per loop and pass)
+        vp.load_isram(0, programs.assemble(programs.poly_mul(n, mods)))
+        vp.load_isram(2048, programs.assemble(programs.poly_mul_batched(n, mods, scratch_row=3 * L * rows)))
         fa, fb = oracle.ntt(a[0], mods[0]), oracle.ntt(b[0], mods[0])
         prod = np.array([(int(x) * int(y)) % mods[0] for x, y in zip(fa, fb)], dtype=np.uint64)
-        assert np.array_equal(got, oracle.intt(prod, mods[0]))
-        t = timeit(run, vp.sync, 100)
-    return {"poly_mul_8_limbs_us": t * 1e6, "fused_min_GBps": 3 * 8 * n * L / t / 1e9,
-            "isa_materialised_GBps": 9 * 8 * n * L / t / 1e9}
+        want = oracle.intt(prod, mods[0])
+        res = {}
+        for name, pc in (("poly_mul_8_limbs_us", 0), ("loop_by_loop_us", 2048)):
+            run = lambda: vp.run(pc, src0=0, src1=L * rows, rslt=2 * L * rows)
+            assert run() == 0
+            assert np.array_equal(vp.read(SPM, 2 * L * rows, n), want)
+            l0 = vp.stats()["kernel_launches"]
+            res[name] = timeit(run, vp.sync, 100) * 1e6
+            res[name.replace("_us", "_launches")] = (vp.stats()["kernel_launches"] - l0) / 101
+    t = res["poly_mul_8_limbs_us"] * 1e-6
+    res.update({"fused_min_GBps": 3 * 8 * n * L / t / 1e9, "isa_materialised_GBps": 9 * 8 * n * L / t / 1e9})
+    return res
 
 
 def config45(L):

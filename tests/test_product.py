@@ -1,0 +1,199 @@
+"""The polynomial product at N = 2^14 as ONE launch (csrc/ntt_product.hip; BASELINE config 3): the sequencer recognises
+`vle; vntt; vle; vntt; vfqmul.vv; vintt; vse` in a program and hands every such limb to one kernel.  GPU == the oracle's
+ISA machine running the same program, word for word; the CPU part checks the kernel's LDS layouts on the host."""
+import numpy as np
+import pytest
+
+import oracle
+from aloha_amd import isa, programs
+from aloha_amd import vp as avp
+
+SPM, KSK = 0, 1
+LOGN, N = 14, 1 << 14
+ROWS = N // 128
+
+
+# ---- CPU: the three register layouts of a 1024-point row under the LDS swizzle (ntt_product.hip) -------------------------
+def _swz(x):
+    return x ^ ((x >> 4) & 31) ^ ((x >> 5) & 31)
+
+
+_LAYOUTS = {
+    "A": lambda l, r: (r << 6) | l,
+    "B": lambda l, r: ((l >> 2) << 6) | (r << 2) | (l & 3),
+    "C": lambda l, r: ((r >> 2) << 8) | (l << 2) | (r & 3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_LAYOUTS))
+def test_row_layouts_are_bijections_without_bank_conflicts(name):
+    lay = _LAYOUTS[name]
+    assert sorted(lay(l, r) for l in range(64) for r in range(16)) == list(range(1024))
+    assert sorted(_swz(x) for x in range(1024)) == list(range(1024))
+    for r in range(16):
+        for half in range(2):                                    # a 64-bit LDS access serves 32 lanes at a time: 32 distinct 8-byte banks
+            banks = {_swz(lay(l, r)) % 32 for l in range(32 * half, 32 * half + 32)}
+            assert len(banks) == 32, (name, r, half)
+
+
+def test_row_layout_twiddle_indices():
+    """Stage s of the transform takes twiddle entry 2^s + (e >> (14 - s)); the kernel's per-layout index arithmetic must say the
+    same for every element a lane holds (rho = row, e = rho * 1024 + x)."""
+    for rho in (0, 5, 15):
+        for l in range(64):
+            for r in range(16):
+                e = rho * 1024 + _LAYOUTS["A"](l, r)
+                for ss in range(4):                              # stages 4..7: wave-uniform, group = top ss bits of r
+                    assert (1 << (4 + ss)) + (e >> (10 - ss)) == (16 << ss) + (rho << ss) + (r >> (4 - ss))
+                e = rho * 1024 + _LAYOUTS["B"](l, r)
+                for ss in range(4):                              # stages 8..11: per lane (hiB = l >> 2)
+                    assert (1 << (8 + ss)) + (e >> (6 - ss)) == (256 << ss) + ((rho * 16 + (l >> 2)) << ss) + (r >> (4 - ss))
+                e = rho * 1024 + _LAYOUTS["C"](l, r)
+                h, rl = r >> 2, r & 3
+                assert (1 << 12) + (e >> 2) == 4096 + rho * 256 + h * 64 + l
+                assert (1 << 13) + (e >> 1) == 8192 + rho * 512 + h * 128 + 2 * l + (rl >> 1)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------------
+def residues(rng, n, q):
+    a = rng.integers(0, q, size=n, dtype=np.uint64)
+    a[:4] = [0, 1, q - 1, q - 2]
+    a[-2:] = [q - 1, 0]
+    return a
+
+
+def run_both(words, inputs, spm_rows, read, launches=None, flags=0, repeat=1, **csr):
+    """inputs: {row: array}; read: (row, words).  Returns the engine's words after checking them against the oracle machine
+    (every repetition: the first run is sequenced, later ones replay its recorded launches)."""
+    o = oracle.OracleVP(spm_rows=spm_rows, ksk_rows=1)
+    for row, data in inputs.items():
+        o.write(SPM, row, data)
+    o.load_isram(0, words)
+    assert o.run(0, **csr) == 0
+    want = o.read(SPM, read[0], read[1])
+    with avp.VP(spm_rows=spm_rows, ksk_rows=1, max_log_n=LOGN, flags=flags) as vp:
+        vp.load_isram(0, words)
+        for rep in range(repeat):
+            for row, data in inputs.items():                     # (in-place programs: every repetition starts from the inputs)
+                vp.write(SPM, row, data)
+            k0 = vp.stats()["kernel_launches"]
+            assert vp.run(0, **csr) == 0
+            vp.sync()
+            if launches is not None:
+                assert vp.stats()["kernel_launches"] - k0 == launches, rep
+            got = vp.read(SPM, read[0], read[1])
+            assert np.array_equal(got, want), rep
+    return got
+
+
+@pytest.mark.gpu
+def test_product_program_is_one_launch_and_equals_the_oracle_machine():
+    L = 8
+    mods = [oracle.nth_prime(LOGN, i) for i in range(L)]
+    rng = np.random.default_rng(314)
+    a = np.concatenate([residues(rng, N, q) for q in mods]); b = np.concatenate([residues(rng, N, q) for q in mods])
+    words = programs.assemble(programs.poly_mul(N, mods))
+    got = run_both(words, {0: a, L * ROWS: b}, 3 * L * ROWS, (2 * L * ROWS, L * N), launches=1, repeat=3,
+                   src0=0, src1=L * ROWS, rslt=2 * L * ROWS)
+    # and the answer is the negacyclic product: one coefficient by direct convolution
+    q, j = mods[0], 4321
+    acc = 0
+    for i in range(N):
+        acc += int(a[i]) * int(b[j - i]) if i <= j else -int(a[i]) * int(b[j - i + N])
+    assert int(got[j]) == acc % q
+
+
+@pytest.mark.gpu
+def test_product_in_place_and_squaring():
+    L = 3
+    mods = [oracle.nth_prime(LOGN, 5 + i) for i in range(L)]
+    rng = np.random.default_rng(315)
+    a = np.concatenate([residues(rng, N, q) for q in mods]); b = np.concatenate([residues(rng, N, q) for q in mods])
+    words = programs.assemble(programs.poly_mul(N, mods))
+    # result over operand a, over operand b, and a * a
+    run_both(words, {0: a, L * ROWS: b}, 2 * L * ROWS, (0, 2 * L * N), launches=1, repeat=2, src0=0, src1=L * ROWS, rslt=0)
+    run_both(words, {0: a, L * ROWS: b}, 2 * L * ROWS, (0, 2 * L * N), launches=1, src0=0, src1=L * ROWS, rslt=L * ROWS)
+    run_both(words, {0: a}, 2 * L * ROWS, (0, 2 * L * N), launches=1, src0=0, src1=0, rslt=L * ROWS)
+
+
+@pytest.mark.gpu
+def test_product_batches_beyond_one_launch_and_mixed_moduli():
+    """70 limbs: two launches (64 + 6), the second on the other counter bank; limbs of one prime and of different primes mixed."""
+    L = 70
+    mods = [oracle.nth_prime(LOGN, (i * 7) % 5) for i in range(L)]
+    rng = np.random.default_rng(316)
+    a = np.concatenate([rng.integers(0, q, N, dtype=np.uint64) for q in mods])
+    b = np.concatenate([rng.integers(0, q, N, dtype=np.uint64) for q in mods])
+    words = programs.assemble(programs.poly_mul(N, mods))
+    with avp.VP(spm_rows=3 * L * ROWS, ksk_rows=1, max_log_n=LOGN) as vp:
+        vp.write(SPM, 0, a); vp.write(SPM, L * ROWS, b)
+        vp.load_isram(0, words)
+        for rep in range(3):                                     # first run sequenced, then replays: the launch count alternates the banks
+            k0 = vp.stats()["kernel_launches"]
+            assert vp.run(0, src0=0, src1=L * ROWS, rslt=2 * L * ROWS) == 0
+            vp.sync()
+            assert vp.stats()["kernel_launches"] - k0 == 2
+            got = vp.read(SPM, 2 * L * ROWS, L * N).reshape(L, N)
+            for j in (0, 1, 63, 64, 69):
+                q = mods[j]
+                fa, fb = oracle.ntt(a[j * N:(j + 1) * N], q), oracle.ntt(b[j * N:(j + 1) * N], q)
+                prod = np.array([(int(x) * int(y)) % q for x, y in zip(fa, fb)], dtype=np.uint64)
+                assert np.array_equal(got[j], oracle.intt(prod, q)), (rep, j)
+        # against the unfused execution of the same program, every limb
+        with avp.VP(spm_rows=3 * L * ROWS, ksk_rows=1, max_log_n=LOGN, flags=avp.FLAG_NO_FUSION) as ref:
+            ref.write(SPM, 0, a); ref.write(SPM, L * ROWS, b)
+            ref.load_isram(0, words)
+            assert ref.run(0, src0=0, src1=L * ROWS, rslt=2 * L * ROWS) == 0
+            ref.sync()
+            assert np.array_equal(ref.read(SPM, 2 * L * ROWS, L * N).reshape(L, N), got)
+
+
+@pytest.mark.gpu
+def test_product_matcher_refusals_still_compute_the_program():
+    """Windows the matcher must NOT turn into a product job: a temporary read afterwards, the product stored as well, a
+    destination that straddles an operand, another ring size.  The programs then run as before (more launches), and equal the
+    oracle machine either way."""
+    q = oracle.nth_prime(LOGN, 2)
+    rng = np.random.default_rng(317)
+    a, b = residues(rng, N, q), residues(rng, N, q)
+    head = [f"vsetvl {64 * N:#x}", f"vsetq {q:#x}"]
+    base = ["vle v0, src0+0x0", "vntt v2, v0", "vle v4, src1+0x0", "vntt v1, v4", "vfqmul.vv v0, v2, v1", "vintt v2, v0"]
+
+    def check(lines, read_words, fused, **csr):
+        words = isa.assemble("\n".join(head + lines + ["break"]))
+        o = oracle.OracleVP(spm_rows=8 * ROWS, ksk_rows=1)
+        with avp.VP(spm_rows=8 * ROWS, ksk_rows=1, max_log_n=LOGN) as vp:
+            out = []
+            for e in (vp, o):
+                e.write(SPM, 0, a); e.write(SPM, ROWS, b)
+                e.load_isram(0, words)
+                k0 = e.stats()["kernel_launches"] if e is vp else 0
+                assert e.run(0, **csr) == 0
+                e.sync()
+                if e is vp:
+                    assert (vp.stats()["kernel_launches"] - k0 == 1) == fused
+                out.append(e.read(SPM, 0, read_words))
+            assert np.array_equal(out[0], out[1])
+
+    csr = dict(src0=0, src1=ROWS, rslt=2 * ROWS)
+    check(base + [f"vse v2, rslt+0x0"], 4 * N, True, **csr)                                              # the pattern itself
+    check(base + [f"vse v2, rslt+0x0", f"vse v1, rslt+{8 * N:#x}"], 4 * N, False, **csr)                 # NTT(b) is read afterwards
+    check(base[:5] + [f"vse v0, rslt+{8 * N:#x}", "vintt v2, v0", "vse v2, rslt+0x0"], 4 * N, False, **csr)   # the product is stored too
+    check(base + [f"vse v2, src0+{4 * N:#x}"], 4 * N, False, **csr)                                      # destination straddles a and b
+    check(base + [f"vse v2, rslt+0x0", "vle v6, rslt+0x0", "vfqadd.vv v3, v6, v1", f"vse v3, rslt+{8 * N:#x}"], 4 * N, False, **csr)
+
+
+@pytest.mark.gpu
+def test_product_followed_and_preceded_by_other_work():
+    """The product job joins the ordinary flow of a program: operands produced by earlier instructions (flushed first),
+    results consumed by later ones."""
+    q = oracle.nth_prime(LOGN, 1)
+    rng = np.random.default_rng(318)
+    a, b = residues(rng, N, q), residues(rng, N, q)
+    lines = [f"vsetvl {64 * N:#x}", f"vsetq {q:#x}",
+             "vle v0, src0+0x0", "vfqadd.vs v2, v0, 0x5", f"vse v2, rslt+{8 * N:#x}",                   # a + 5 -> rslt limb 1
+             f"vle v0, rslt+{8 * N:#x}", "vntt v2, v0", "vle v4, src1+0x0", "vntt v1, v4", "vfqmul.vv v0, v2, v1", "vintt v2, v0",
+             "vse v2, rslt+0x0",                                                                         # (a + 5) * b -> rslt limb 0
+             "vle v0, rslt+0x0", "vfqmul.vs v2, v0, 0x3", f"vse v2, rslt+{16 * N:#x}", "break"]          # 3 * that -> rslt limb 2
+    words = isa.assemble("\n".join(lines))
+    run_both(words, {0: a, ROWS: b}, 6 * ROWS, (2 * ROWS, 3 * N), launches=3, repeat=2, src0=0, src1=ROWS, rslt=2 * ROWS)
