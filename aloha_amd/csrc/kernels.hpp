@@ -238,11 +238,12 @@ struct ProdJob {
   uint32_t prime, pad;
 };
 constexpr uint32_t kProdMaxLimbs = 64;           // limbs per launch
-size_t poly_product_ctl_words();                 // u32 words of control memory (arrival counters in two banks + a status word), zeroed once
-// d_work: 2 * count * 2^14 words of scratch (the transforms' intermediates); gen: the handle's count of product launches
-// (selects the counter bank); the last word of d_ctl is sticky: non-zero after a launch gave up on a bounded wait
-hipError_t poly_product_batch(hipStream_t st, const ProdJob *d_jobs, const PrimeDev *d_primes, uint32_t count, u64 *d_work, uint32_t *d_ctl,
-                              uint32_t gen, uint64_t *launches);
+// d_work: poly_product_work_words() words of scratch: three intermediates per limb slot, every word tagged in its top two
+// bits with the launch that wrote it -- `tag` must differ from the tag the slots [0, count) carry (0 after a memset);
+// d_status: one sticky u32, non-zero after a launch gave up on a bounded wait
+size_t poly_product_work_words();
+hipError_t poly_product_batch(hipStream_t st, const ProdJob *d_jobs, const PrimeDev *d_primes, uint32_t count, u64 *d_work, uint32_t *d_status,
+                              uint32_t tag, uint64_t *launches);
 
 // ---- measurement helpers (ew_kernels.hip) ---------------------------------------------------------------
 // limb i of `count` limbs of n words at base + i*n: the first n accepted candidates (top 60 bits, < moduli[i]) of the

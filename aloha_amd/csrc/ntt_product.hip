@@ -13,13 +13,15 @@
 //                                      operand-a wave through LDS (one workgroup barrier), which multiplies and runs the
 //                                      inverse stages 13..4 the same way backwards
 //   P3  inverse stages 3..0, N^-1      the mirror of P1, canonical results to the destination
-// Workgroups of a later phase follow those of an earlier one in the grid and wait for them: per limb one arrival counter
-// for each operand's P1 workgroups and one for its P2 rows.  Progress needs only that every XCD dispatches its share of
-// the grid in order (a waiting workgroup's producers have smaller indices, so they are resident or done); every wait is
-// bounded and reports through a sticky status word.  Visibility (MI355X guide, "valid forms"): every handed-over byte is
-// stored sc1 and drained (s_waitcnt vmcnt(0)) before ONE lane of the storing workgroup adds to the counter (agent scope);
-// the consumer's wave polls the counter with sc1 loads and only then loads the bytes, every one with an sc1 load.
-// Counters live in two banks used by alternate launches: a launch zeroes the bank its successor will use.
+// Workgroups of a later phase follow those of an earlier one in the grid and wait for their data.  The hand-off is
+// DATA-TAGGED: every intermediate word is < 4q < 2^62 and carries the launch's 2-bit tag in its top bits, written by ONE
+// 8-byte sc1 (write-through) store; a consumer loads the words it needs with sc1 loads and repeats until every one shows
+// the tag (MI355X guide, hand-off by tagged 8-byte granules: no flag, no ordering between stores, no drain at the
+// producer).  Against arrival counters (stores drained, one atomic per workgroup, a poll of the counter, then the loads)
+// this takes ~1.7 us off each of the two hops (tests/perf/product_trace.py, profiles/r03_*product_trace*).  The host never
+// reuses the tag a slot's words still carry (vp_engine.cpp keeps the last tag per limb slot).  Progress needs only that
+// every XCD dispatches its share of the grid in order (a waiting workgroup's producers have smaller indices, so they are
+// resident or done); every wait is bounded and reports through a sticky status word.
 // Arithmetic, twiddle tables and results are those of ntt_single.hip (the same steps, cut at the region boundary):
 // bit-exact against the oracle's ISA machine in tests/test_product.py.
 #include "kernels.hpp"
@@ -35,15 +37,12 @@ constexpr int PLOGN = 14, PN = 1 << PLOGN, PR = PN / 16;     // row length 1024
 constexpr uint32_t kP1PerOp = PR / 128;                      // P1 workgroups (128 threads) per limb and operand: 8
 constexpr uint32_t kP2PerLimb = 16;                          // P2 workgroups per limb: one per row
 constexpr uint32_t kP3PerLimb = PR / 128;                    // 8
-constexpr uint32_t kCtr = 16;                                // u32 words between counters (64 bytes)
-constexpr uint32_t kBankWords = kProdMaxLimbs * 3 * kCtr;    // counters of one bank
-constexpr uint32_t kSpinLimit = 1u << 17;                    // polls before a wait gives up (~30 ms)
+constexpr uint32_t kSpinLimit = 1u << 15;                    // sweeps before a wait gives up (~30 ms)
+constexpr u64 kTagMask = 3ull << 62;
 
 typedef ALOHA_AS_GLOBAL uint32_t *gu32_t;
 __device__ __forceinline__ u64 ld_handoff(cgptr_t p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }       // global_load_dwordx2 sc1
-__device__ __forceinline__ void st_handoff(gptr_t p, u64 x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }    // global_store_dwordx2 sc0 sc1
-__device__ __forceinline__ uint32_t ld_ctr(gu32_t p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void st_handoff(gptr_t p, u64 x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }    // global_store_dwordx2 sc1
 
 // LDS word of element x of a 1024-point row: ntt_single.hip's swizzle, under which the three layouts below touch 32
 // distinct 8-byte banks per half-wave (checked exhaustively on the host, tests/test_product.py)
@@ -74,16 +73,36 @@ __device__ __forceinline__ void preload15(tw_t (&t)[15], ctw_t tab, uint32_t bas
     for (int g = 0; g < (1 << ss); g++) t[(1 << ss) - 1 + g] = ld_tw_now(tab + (base << ss) + (a << ss) + g);
 }
 
-// wait until *ctr >= target: lane 0 polls, the wave reconverges behind it
-__device__ __forceinline__ void wait_counter(gu32_t ctr, uint32_t target, gu32_t status, int lane) {
-  if (lane == 0) {
-    uint32_t spins = 0;
-    while (ld_ctr(ctr) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > kSpinLimit) { __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+// the wave's 16 x 64 tagged words at p + off(r): swept with sc1 loads until every word of every lane carries `tag`
+// (bits 63..62); returns them with the tag removed
+template <class OFF>
+__device__ __forceinline__ void load_tagged(u64 (&v)[16], cgptr_t p, const OFF &off, u64 tag, gu32_t status) {
+  uint32_t sweeps = 0;
+  for (;;) {
+    u64 bad = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      v[r] = ld_handoff(p + off(r));
+      bad |= v[r] ^ tag;
     }
+    if (__builtin_amdgcn_ballot_w64((bad & kTagMask) != 0) == 0) break;
+    if (++sweeps > kSpinLimit) {                                 // (cannot happen in a correct schedule: reported, not hung on)
+      if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+        __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
   }
-  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; r++) v[r] &= ~kTagMask;
+}
+
+// values < B*q  ->  < 4q (borrow-subtracts of ceil(b/2)*q, as in the transforms' range plans); tagged_bound: what is left
+constexpr int tagged_bound(int b) { while (b > 4) b = (b + 1) / 2; return b; }
+template <int B>
+__device__ __forceinline__ u64 below_4q(u64 x, u64 q) {
+  if constexpr (B <= 4) return x;
+  else return below_4q<(B + 1) / 2>(csub_u(x, q * (u64)((B + 1) / 2)), q);
 }
 
 // Variant builds with -DALOHA_PROD_TRACE: every workgroup leaves constant-rate clock stamps (100 MHz) of its steps in the
@@ -96,23 +115,20 @@ __device__ __forceinline__ void wait_counter(gu32_t ctr, uint32_t target, gu32_t
 #define PROD_STAMP_VM(slot) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void poly_product_kernel(const ProdJob *__restrict__ jobs, const PrimeDev *__restrict__ primes,
-                                                           u64 *__restrict__ work, uint32_t *__restrict__ ctl, uint32_t count, uint32_t gen) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void poly_product_kernel(
+    const ProdJob *__restrict__ jobs, const PrimeDev *__restrict__ primes, u64 *__restrict__ work, uint32_t *__restrict__ status_, uint32_t count, uint32_t tag_) {
   __shared__ u64 lds[2 * PR];
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t wv = uni(tid >> 6);
   const uint32_t b = blockIdx.x;
   const uint32_t nP1 = count * 2 * kP1PerOp, nP2 = count * kP2PerLimb;
-  gu32_t bank = (gu32_t)ctl + (gen & 1) * kBankWords;
-  gu32_t status = (gu32_t)ctl + 2 * kBankWords;
+  gu32_t status = (gu32_t)status_;
+  const u64 tag = (u64)(tag_ & 3) << 62;
 #ifdef ALOHA_PROD_TRACE
-  u64 *trace = work + (size_t)2 * kProdMaxLimbs * PN;
+  u64 *trace = work + (size_t)3 * kProdMaxLimbs * PN;
 #endif
   PROD_STAMP(0);
-  if (b == 0) {                                                  // the other bank: the NEXT launch's counters
-    gu32_t other = (gu32_t)ctl + ((gen + 1) & 1) * kBankWords;
-    for (uint32_t i = tid; i < kProdMaxLimbs * 3; i += 128) __hip_atomic_store(other + i * kCtr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  constexpr int BI = tagged_bound(bound_after4(FWD_IN));         // bound of a tagged forward intermediate (P1's output after below_4q)
   if (b < nP1) {
     // ---- P1: forward stages 0..3 of one operand, 128 columns ------------------------------------------------------------
     const uint32_t limb = b / (2 * kP1PerOp), idx = b % (2 * kP1PerOp), op = idx / kP1PerOp, t = (idx % kP1PerOp) * 128 + tid;
@@ -120,20 +136,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const PrimeDev *pr = &primes[jb.prime];
     const u64 q = pr->m.q, nq = pr->m.nq;
     cgptr_t src = (cgptr_t)(op ? jb.b : jb.a) + t;
-    gptr_t w = (gptr_t)work + (size_t)(2 * limb + op) * PN + t;
+    gptr_t w = (gptr_t)work + (size_t)(3 * limb + op) * PN + t;
     u64 v[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = ld_stream(src + r * PR);
     PROD_STAMP_VM(4);
     fwd_radix16<true, FWD_IN>(v, TwRow{(ctw_t)pr->tw.fwd, 1, 0}, q, nq);
+    constexpr int B1 = bound_after4(FWD_IN);
+    static_assert(B1 <= 16 && BI <= 4, "P1's output does not fit the tagged format");
     PROD_STAMP(1);
 #pragma unroll
-    for (int r = 0; r < 16; r++) st_handoff(w + r * PR, v[r]);
-    drain_stores();
+    for (int r = 0; r < 16; r++) st_handoff(w + r * PR, below_4q<B1>(v[r], q) | tag);
     PROD_STAMP(2);
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(bank + (limb * 3 + op) * kCtr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    PROD_STAMP(3);
     return;
   }
   if (b < nP1 + nP2) {
@@ -144,7 +158,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const u64 q = pr->m.q, nq = pr->m.nq;
     ctw_t ftab = (ctw_t)pr->tw.fwd;
     u64 *my = lds + wv * PR;
-    gptr_t row = (gptr_t)work + (size_t)(2 * limb + wv) * PN + rho * PR;   // wave 0: operand a, wave 1: operand b
+    cgptr_t row = (cgptr_t)work + (size_t)(3 * limb + wv) * PN + rho * PR;    // wave 0: operand a, wave 1: operand b
     const uint32_t hiB = lane >> 2;
     // A wave alone on its SIMD has nothing to hide a load's latency behind: every per-lane twiddle of the forward steps and
     // of the first inverse step is requested BEFORE the wait for the producers (156 VGPRs; the wave may use 256), the second
@@ -155,20 +169,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
     for (int h = 0; h < 4; h++) tw12[h] = ld_tw_now(ftab + 4096 + rho * 256 + h * 64 + lane);
 #pragma unroll
-    for (int i = 0; i < 8; i++) tw13[i] = ld_tw_now(ftab + 8192 + rho * 512 + (i >> 1) * 128 + 2 * lane + (i & 1));
+    for (int j = 0; j < 8; j++) tw13[j] = ld_tw_now(ftab + 8192 + rho * 512 + (j >> 1) * 128 + 2 * lane + (j & 1));
     if (!wv) {
 #pragma unroll
-      for (int i = 0; i < 8; i++) itw13[i] = ld_tw_now(itab + 8192 + rho * 512 + (i >> 1) * 128 + 2 * lane + (i & 1));
+      for (int j = 0; j < 8; j++) itw13[j] = ld_tw_now(itab + 8192 + rho * 512 + (j >> 1) * 128 + 2 * lane + (j & 1));
 #pragma unroll
       for (int h = 0; h < 4; h++) itw12[h] = ld_tw_now(itab + 4096 + rho * 256 + h * 64 + lane);
     }
-    wait_counter(bank + (limb * 3 + wv) * kCtr, kP1PerOp, status, lane);
-    PROD_STAMP(1);
     u64 v[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = ld_handoff((cgptr_t)row + layA(lane, r));
-    PROD_STAMP_VM(2);
-    constexpr int B1 = bound_after4(FWD_IN), B2 = bound_after4(B1), B3 = bound_after4(B2), B4 = next_bound(B3), B5 = next_bound(B4);
+    load_tagged(v, row, [&](int r) { return layA(lane, r); }, tag, status);
+    PROD_STAMP(2);
+    constexpr int B1 = BI, B2 = bound_after4(B1), B3 = bound_after4(B2), B4 = next_bound(B3), B5 = next_bound(B4);
     static_assert(B1 <= 16 && B2 <= 16 && B3 <= 16 && B4 <= 16 && B5 <= 16, "forward lazy range overflows");
     fwd_radix16<true, B1>(v, TwRow{ftab, 16, rho}, q, nq);                                // stages 4..7
     PROD_STAMP(3);
@@ -257,10 +268,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     PROD_STAMP(14);
     inv_radix16<true, INV_MID, false>(v, TwRow{itab, 16, rho}, q, nq);                    // stages 7..4
     PROD_STAMP(15);
+    gptr_t out = (gptr_t)work + (size_t)(3 * limb + 2) * PN + rho * PR;
 #pragma unroll
-    for (int r = 0; r < 16; r++) st_handoff(row + layA(lane, r), v[r]);                   // < 4q, over operand a's row
-    drain_stores();
-    if (lane == 0) __hip_atomic_fetch_add(bank + (limb * 3 + 2) * kCtr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int r = 0; r < 16; r++) st_handoff(out + layA(lane, r), v[r] | tag);             // < 4q (INV_MID)
     return;
   }
   {
@@ -269,15 +279,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const ProdJob jb = jobs[limb];
     const PrimeDev *pr = &primes[jb.prime];
     const u64 q = pr->m.q, nq = pr->m.nq;
-    cgptr_t w = (cgptr_t)work + (size_t)(2 * limb) * PN + t;
+    cgptr_t w = (cgptr_t)work + (size_t)(3 * limb + 2) * PN + t;
     gptr_t dst = (gptr_t)jb.d + t;
     const LastScale ls = last_scale<false>(nullptr, pr);
-    wait_counter(bank + (limb * 3 + 2) * kCtr, kP2PerLimb, status, lane);
-    PROD_STAMP(1);
     u64 v[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = ld_handoff(w + r * PR);
-    PROD_STAMP_VM(4);
+    load_tagged(v, w, [&](int r) { return (uint32_t)r * PR; }, tag, status);
+    PROD_STAMP(4);
     inv_radix16<true, INV_MID, true>(v, TwRow{(ctw_t)pr->tw.inv, 1, 0}, q, nq, ls.w, ls.ni, ls.nip);
     PROD_STAMP(2);
 #pragma unroll
@@ -288,14 +295,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
 }  // namespace
 
-size_t poly_product_ctl_words() { return 2 * kBankWords + kCtr; }
+size_t poly_product_work_words() { return (size_t)3 * kProdMaxLimbs * PN; }
 
-hipError_t poly_product_batch(hipStream_t st, const ProdJob *d_jobs, const PrimeDev *d_primes, uint32_t count, u64 *d_work, uint32_t *d_ctl,
-                              uint32_t gen, uint64_t *launches) {
+hipError_t poly_product_batch(hipStream_t st, const ProdJob *d_jobs, const PrimeDev *d_primes, uint32_t count, u64 *d_work, uint32_t *d_status,
+                              uint32_t tag, uint64_t *launches) {
   if (!count) return hipSuccess;
   if (count > kProdMaxLimbs) return hipErrorInvalidValue;
   const uint32_t grid = count * (2 * kP1PerOp + kP2PerLimb + kP3PerLimb);
-  hipLaunchKernelGGL(poly_product_kernel, dim3(grid), dim3(128), 0, st, d_jobs, d_primes, d_work, d_ctl, count, gen);
+  hipLaunchKernelGGL(poly_product_kernel, dim3(grid), dim3(128), 0, st, d_jobs, d_primes, d_work, d_status, count, tag);
   if (launches) ++*launches;
   return hipGetLastError();
 }

@@ -127,7 +127,7 @@ struct aloha_vp {
   // counters (two banks, used by alternate launches) with a sticky status word behind them; allocated at the first product
   u64 *d_prod_work = nullptr;
   uint32_t *d_prod_ctl = nullptr;
-  uint32_t prod_gen = 0;                             // product launches so far
+  uint8_t prod_tag[aloha::k::kProdMaxLimbs] = {0};   // the tag the words of each limb slot of d_prod_work carry (0: as allocated)
   bool prod_unchecked = false;                       // a product launch ran since the status word was last read
   // Launch lists of whole program runs, replayed when the same program segment is run again with the same CSRs
   // and the same architectural state on entry: the sequencer is a pure function of those (no data-dependent
@@ -330,13 +330,11 @@ aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
 aloha_status check_product(aloha_vp *vp) {
   if (!vp->prod_unchecked) return ALOHA_OK;
   uint32_t st = 0;
-  uint32_t *word = vp->d_prod_ctl + aloha::k::poly_product_ctl_words() - 16;
-  HIPCK(vp, hipMemcpyAsync(&st, word, 4, hipMemcpyDeviceToHost, vp->stream));
+  HIPCK(vp, hipMemcpyAsync(&st, vp->d_prod_ctl, 4, hipMemcpyDeviceToHost, vp->stream));
   HIPCK(vp, hipStreamSynchronize(vp->stream));
   vp->prod_unchecked = false;
   if (!st) return ALOHA_OK;
-  HIPCK(vp, hipMemsetAsync(vp->d_prod_ctl, 0, aloha::k::poly_product_ctl_words() * 4, vp->stream));
-  vp->prod_gen = 0;
+  HIPCK(vp, hipMemsetAsync(vp->d_prod_ctl, 0, 64, vp->stream));
   return fail(vp, ALOHA_ERR_DEVICE, "a fused polynomial product gave up on a bounded wait (%u waits): its output is incomplete", st);
 }
 
@@ -701,7 +699,7 @@ aloha_status aloha_vp_load_isram_hex(aloha_vp *vp, uint32_t base_pc, const char 
 aloha_status aloha_vp_debug_product_trace(aloha_vp *vp, void *dst, uint64_t bytes) {
   if (!vp || !dst || !vp->d_prod_work || bytes > (1u << 20)) return ALOHA_ERR_ARG;
   DeviceGuard dev_guard(vp);
-  HIPCK(vp, hipMemcpyAsync(dst, vp->d_prod_work + ((size_t)aloha::k::kProdMaxLimbs * 2 << 14), bytes, hipMemcpyDeviceToHost, vp->stream));
+  HIPCK(vp, hipMemcpyAsync(dst, vp->d_prod_work + aloha::k::poly_product_work_words(), bytes, hipMemcpyDeviceToHost, vp->stream));
   HIPCK(vp, hipStreamSynchronize(vp->stream));
   return ALOHA_OK;
 }
@@ -1395,15 +1393,17 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
       s = launch_dots(dot_batch, batch_logn);
     }
     else if (pend_kind == PK_PROD && !prod_batch.empty()) {
-      if (!vp->d_prod_ctl) {                                   // first product of this handle: scratch and counters
-        const size_t cw = aloha::k::poly_product_ctl_words() * 4, ww = ((size_t)aloha::k::kProdMaxLimbs * 2 * 8 << 14) + (1u << 20);   // (+ 1 MiB: clock stamps of trace builds)
-        if (hipMalloc(&vp->d_prod_work, ww) != hipSuccess || hipMalloc(&vp->d_prod_ctl, cw) != hipSuccess ||
-            hipMemsetAsync(vp->d_prod_ctl, 0, cw, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+      if (!vp->d_prod_ctl) {                                   // first product of this handle: scratch (tag 0 everywhere) and the status word
+        const size_t ww = aloha::k::poly_product_work_words() * 8 + (1u << 20);   // (+ 1 MiB: clock stamps of trace builds)
+        if (hipMalloc(&vp->d_prod_work, ww) != hipSuccess || hipMalloc(&vp->d_prod_ctl, 64) != hipSuccess ||
+            hipMemsetAsync(vp->d_prod_work, 0, ww, st) != hipSuccess || hipMemsetAsync(vp->d_prod_ctl, 0, 64, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
           if (vp->d_prod_work) (void)hipFree(vp->d_prod_work);
           if (vp->d_prod_ctl) (void)hipFree(vp->d_prod_ctl);
           vp->d_prod_work = nullptr; vp->d_prod_ctl = nullptr;
           s = fail(vp, ALOHA_ERR_DEVICE, "polynomial product: scratch allocation failed");
         }
+        memset(vp->prod_tag, 0, sizeof vp->prod_tag);
       }
       for (size_t j0 = 0; !s && j0 < prod_batch.size(); j0 += aloha::k::kProdMaxLimbs) {
         const uint32_t nj = (uint32_t)std::min<size_t>(aloha::k::kProdMaxLimbs, prod_batch.size() - j0);
@@ -1411,9 +1411,21 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         s = device_blob(vp, prod_batch.data() + j0, nj * sizeof(prod_batch[0]), &dj);
         if (s) break;
         const hipError_t e = issue(vp, [=]() -> hipError_t {
+          // a tag none of the slots [0, nj) still carries (slots a smaller launch skipped keep older tags); if launches of
+          // different sizes have left all four behind, the slots are wiped first
+          uint32_t used = 0;
+          for (uint32_t i = 0; i < nj; i++) used |= 1u << vp->prod_tag[i];
+          if (used == 15u) {
+            const hipError_t em = hipMemsetAsync(vp->d_prod_work, 0, (size_t)nj * 3 * 8 << 14, st);
+            if (em != hipSuccess) return em;
+            used = 1u;
+          }
+          uint32_t tag = 1;
+          while (used & (1u << tag)) tag = (tag + 1) & 3;
+          for (uint32_t i = 0; i < nj; i++) vp->prod_tag[i] = (uint8_t)tag;
           uint64_t launches = 0;
           const hipError_t e2 = aloha::k::poly_product_batch(st, (const aloha::k::ProdJob *)dj, vp->d_primes, nj, vp->d_prod_work, vp->d_prod_ctl,
-                                                             vp->prod_gen++, &launches);
+                                                             tag, &launches);
           vp->stats.kernel_launches += launches;
           vp->prod_unchecked = true;
           return e2;

@@ -40,11 +40,11 @@ t = buf.reshape(nwg, 16).astype(np.int64)
 t0 = t[:, 0].min()
 us = (t - t0) / 100.0                                            # 100 MHz -> microseconds
 nP1, nP2 = L * 16, L * 16
-P1 = {0: "start", 4: "operand loaded", 1: "radix-16 done", 2: "stores drained", 3: "signalled"}
-P2 = {0: "start", 1: "poll matched", 2: "row loaded", 3: "stages 4-7 done", 4: "exchange A->B done", 5: "stages 8-11 done",
+P1 = {0: "start", 4: "operand loaded", 1: "radix-16 done", 2: "stores issued"}
+P2 = {0: "start", 2: "row loaded (all tags seen)", 3: "stages 4-7 done", 4: "exchange A->B done", 5: "stages 8-11 done",
       6: "exchange B->C done", 7: "stages 12-13 done", 8: "canonical, b's row in LDS", 9: "barrier passed", 10: "product done",
       11: "inverse 13-12 done", 12: "exchange C->B done", 13: "inverse 11-8 done", 14: "exchange B->A done", 15: "inverse 7-4 done"}
-P3 = {0: "start", 1: "poll matched", 4: "columns loaded", 2: "radix-16 done", 3: "stores issued"}
+P3 = {0: "start", 4: "columns loaded (all tags seen)", 2: "radix-16 done", 3: "stores issued"}
 for name, a, steps in (("P1", us[:nP1], P1), ("P2 (operand a's wave)", us[nP1:nP1 + nP2], P2), ("P3", us[nP1 + nP2:], P3)):
     print(name)
     prev = None
