@@ -34,9 +34,10 @@ namespace k {
 namespace {
 
 constexpr int PLOGN = 14, PN = 1 << PLOGN, PR = PN / 16;     // row length 1024
-constexpr uint32_t kP1PerOp = PR / 128;                      // P1 workgroups (128 threads) per limb and operand: 8
+constexpr uint32_t kWG = 256;                                // threads per workgroup
+constexpr uint32_t kP1PerOp = 2 * PR / kWG;                  // P1 workgroups per limb and operand: 8 (128 columns x two halves of the outputs)
 constexpr uint32_t kP2PerLimb = 16;                          // P2 workgroups per limb: one per row
-constexpr uint32_t kP3PerLimb = PR / 128;                    // 8
+constexpr uint32_t kP3PerLimb = 2 * PR / kWG;                // 8
 constexpr uint32_t kSpinLimit = 1u << 15;                    // sweeps before a wait gives up (~30 ms)
 constexpr u64 kTagMask = 3ull << 62;
 
@@ -44,13 +45,14 @@ typedef ALOHA_AS_GLOBAL uint32_t *gu32_t;
 __device__ __forceinline__ u64 ld_handoff(cgptr_t p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }       // global_load_dwordx2 sc1
 __device__ __forceinline__ void st_handoff(gptr_t p, u64 x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }    // global_store_dwordx2 sc1
 
-// LDS word of element x of a 1024-point row: ntt_single.hip's swizzle, under which the three layouts below touch 32
-// distinct 8-byte banks per half-wave (checked exhaustively on the host, tests/test_product.py)
-__device__ __forceinline__ uint32_t swz(uint32_t x) { return x ^ ((x >> 4) & 31) ^ ((x >> 5) & 31); }
-// layouts of a row in a wave: register r of lane l holds x =
-__device__ __forceinline__ uint32_t layA(uint32_t l, uint32_t r) { return (r << 6) | l; }                               // registers = bits 9..6
-__device__ __forceinline__ uint32_t layB(uint32_t l, uint32_t r) { return ((l >> 2) << 6) | (r << 2) | (l & 3); }      // registers = bits 5..2
-__device__ __forceinline__ uint32_t layC(uint32_t l, uint32_t r) { return ((r >> 2) << 8) | (l << 2) | (r & 3); }      // registers = bits 9..8, 1..0
+// A half row (512 points, 8 per lane) in LDS: word y ^ ((y >> 3) & 31) -- a bijection under which the three layouts below
+// touch 32 distinct 8-byte banks per half-wave (checked exhaustively on the host, tests/test_product.py); register r of
+// lane l holds y =
+constexpr int PH = PR / 2;
+__device__ __forceinline__ uint32_t swh(uint32_t y) { return y ^ ((y >> 3) & 31); }
+__device__ __forceinline__ uint32_t lay1(uint32_t l, uint32_t r) { return (r << 6) | l; }                               // registers = bits 8..6
+__device__ __forceinline__ uint32_t lay2(uint32_t l, uint32_t r) { return ((l >> 3) << 6) | (r << 3) | (l & 7); }      // registers = bits 5..3
+__device__ __forceinline__ uint32_t lay3(uint32_t l, uint32_t r) { return (l << 3) | r; }                              // registers = bits 2..0
 
 struct TwRow {                     // entries 2^(S0+ss) + a*2^ss + g of the plain (w, w') table
   ctw_t tab;
@@ -73,15 +75,67 @@ __device__ __forceinline__ void preload15(tw_t (&t)[15], ctw_t tab, uint32_t bas
     for (int g = 0; g < (1 << ss); g++) t[(1 << ss) - 1 + g] = ld_tw_now(tab + (base << ss) + (a << ss) + g);
 }
 
-// the wave's 16 x 64 tagged words at p + off(r): swept with sc1 loads until every word of every lane carries `tag`
+__device__ __forceinline__ void preload7(tw_t (&t)[7], ctw_t tab, uint32_t base, uint32_t a) {
+#pragma unroll
+  for (int ss = 0; ss < 3; ss++)
+#pragma unroll
+    for (int g = 0; g < (1 << ss); g++) t[(1 << ss) - 1 + g] = ld_tw_now(tab + (base << ss) + (a << ss) + g);
+}
+struct TwReg7 {                    // the 7 twiddles of a radix-8 step from registers: index 2^ss - 1 + g
+  const tw_t (&r)[7];
+  __device__ __forceinline__ tw_t operator()(int ss, int g) const { return r[(1 << ss) - 1 + g]; }
+};
+
+// radix-8 register steps: sub-stage ss pairs v[i] with v[i + (4 >> ss)], group g of sub-stage ss takes tw(ss, g) -- the
+// radix-16 steps of ntt_device.hpp with three sub-stages.  Forward: relaxed butterflies on the lazy-range plan (BIN -> bound_after3(BIN));
+// inverse: Gentleman-Sande butterflies, every value < 4q before and after.
+constexpr int bound_after3(int b) { return next_bound(next_bound(next_bound(b))); }
+template <bool UNI, int BIN, typename TW>
+__device__ __forceinline__ void fwd_radix8(u64 (&v)[8], const TW &tw, u64 q, u64 nq) {
+  constexpr int B[3] = {BIN, next_bound(BIN), next_bound(next_bound(BIN))};
+  const u64 fourq = q << 2;
+#pragma unroll
+  for (int ss = 0; ss < 3; ss++) {
+    const int half = 4 >> ss;
+#pragma unroll
+    for (int g = 0; g < (1 << ss); g++) {
+      const tw_t t = tw(ss, g);
+#pragma unroll
+      for (int jj = 0; jj < half; jj++) {
+        const int i0 = g * 2 * half + jj;
+        if (need_corr(B[ss])) v[i0] = csub_u(v[i0], q * (u64)corr_t(B[ss]));
+        ct_bfly<UNI, false>(v[i0], v[i0 + half], t.w, t.wp, nq, fourq);
+      }
+    }
+  }
+}
+template <bool UNI, typename TW>
+__device__ __forceinline__ void inv_radix8(u64 (&v)[8], const TW &tw, u64 q, u64 nq) {
+  const u64 fourq = q << 2;
+#pragma unroll
+  for (int idx = 0; idx < 3; idx++) {
+    const int ss = 2 - idx, half = 4 >> ss;
+#pragma unroll
+    for (int g = 0; g < (1 << ss); g++) {
+      const tw_t t = tw(ss, g);
+#pragma unroll
+      for (int jj = 0; jj < half; jj++) {
+        const int i0 = g * 2 * half + jj;
+        gs_bfly<UNI>(v[i0], v[i0 + half], t.w, t.wp, nq, fourq);
+      }
+    }
+  }
+}
+
+// the wave's NV x 64 tagged words at p + off(r): swept with sc1 loads until every word of every lane carries `tag`
 // (bits 63..62); returns them with the tag removed
-template <class OFF>
-__device__ __forceinline__ void load_tagged(u64 (&v)[16], cgptr_t p, const OFF &off, u64 tag, gu32_t status) {
+template <int NV, class OFF>
+__device__ __forceinline__ void load_tagged(u64 (&v)[NV], cgptr_t p, const OFF &off, u64 tag, gu32_t status) {
   uint32_t sweeps = 0;
   for (;;) {
     u64 bad = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < NV; r++) {
       v[r] = ld_handoff(p + off(r));
       bad |= v[r] ^ tag;
     }
@@ -94,7 +148,7 @@ __device__ __forceinline__ void load_tagged(u64 (&v)[16], cgptr_t p, const OFF &
     __builtin_amdgcn_s_sleep(1);
   }
 #pragma unroll
-  for (int r = 0; r < 16; r++) v[r] &= ~kTagMask;
+  for (int r = 0; r < NV; r++) v[r] &= ~kTagMask;
 }
 
 // values < B*q  ->  < 4q (borrow-subtracts of ceil(b/2)*q, as in the transforms' range plans); tagged_bound: what is left
@@ -115,9 +169,9 @@ __device__ __forceinline__ u64 below_4q(u64 x, u64 q) {
 #define PROD_STAMP_VM(slot) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void poly_product_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void poly_product_kernel(
     const ProdJob *__restrict__ jobs, const PrimeDev *__restrict__ primes, u64 *__restrict__ work, uint32_t *__restrict__ status_, uint32_t count, uint32_t tag_) {
-  __shared__ u64 lds[2 * PR];
+  __shared__ u64 lds[4 * PH];
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t wv = uni(tid >> 6);
   const uint32_t b = blockIdx.x;
@@ -131,164 +185,182 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   constexpr int BI = tagged_bound(bound_after4(FWD_IN));         // bound of a tagged forward intermediate (P1's output after below_4q)
   if (b < nP1) {
     // ---- P1: forward stages 0..3 of one operand, 128 columns ------------------------------------------------------------
-    const uint32_t limb = b / (2 * kP1PerOp), idx = b % (2 * kP1PerOp), op = idx / kP1PerOp, t = (idx % kP1PerOp) * 128 + tid;
+    // Two waves per 64 columns, as in P2: stage 0 pairs row r with r + 8, both waves load all 16 rows and each keeps its half
+    // of that stage's outputs (rows 8 hh + j), then runs stages 1..3 on its 8 values and stores 8.
+    const uint32_t limb = b / (2 * kP1PerOp), idx = b % (2 * kP1PerOp), op = idx / kP1PerOp;
+    const uint32_t hh = uni(tid >> 7), t = (idx % kP1PerOp) * 128 + (tid & 127);
     const ProdJob jb = jobs[limb];
     const PrimeDev *pr = &primes[jb.prime];
     const u64 q = pr->m.q, nq = pr->m.nq;
+    ctw_t ftab = (ctw_t)pr->tw.fwd;
     cgptr_t src = (cgptr_t)(op ? jb.b : jb.a) + t;
-    gptr_t w = (gptr_t)work + (size_t)(3 * limb + op) * PN + t;
-    u64 v[16];
+    gptr_t w = (gptr_t)work + (size_t)(3 * limb + op) * PN + hh * (8 * PR) + t;
+    u64 v[16], u[8];
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = ld_stream(src + r * PR);
     PROD_STAMP_VM(4);
-    fwd_radix16<true, FWD_IN>(v, TwRow{(ctw_t)pr->tw.fwd, 1, 0}, q, nq);
-    constexpr int B1 = bound_after4(FWD_IN);
-    static_assert(B1 <= 16 && BI <= 4, "P1's output does not fit the tagged format");
+    constexpr int B0 = next_bound(FWD_IN), B1 = bound_after3(B0);
+    static_assert(!need_corr(FWD_IN) && B1 <= 16 && BI <= 4 && B1 == bound_after4(FWD_IN), "P1's output does not fit the tagged format");
+    {
+      const tw_t w0 = load_tw(ftab + 1);                         // stage 0
+      const u64 fourq = q << 2;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        ct_bfly<true, false>(v[j], v[j + 8], w0.w, w0.wp, nq, fourq);
+        u[j] = hh ? v[j + 8] : v[j];
+      }
+    }
+    fwd_radix8<true, B0>(u, TwRow{ftab, 2, hh}, q, nq);                                   // stages 1..3
     PROD_STAMP(1);
 #pragma unroll
-    for (int r = 0; r < 16; r++) st_handoff(w + r * PR, below_4q<B1>(v[r], q) | tag);
+    for (int j = 0; j < 8; j++) st_handoff(w + j * PR, below_4q<B1>(u[j], q) | tag);
     PROD_STAMP(2);
     return;
   }
   if (b < nP1 + nP2) {
     // ---- P2: one row of both operands: forward stages 4..13, product, inverse stages 13..4 ------------------------------------
+    // Four waves: (operand, half of the row).  Stages 5..13 stay inside a half; stage 4 pairs x with x + 512, so for the
+    // forward transform both waves of an operand load the whole row and each keeps its half of that stage's outputs (8
+    // redundant products per lane instead of an exchange); for the inverse the halves meet in LDS.  A half is 512 points =
+    // 8 per lane: three radix-8 register steps, two wave-private exchanges.
     const uint32_t i = b - nP1, limb = i / kP2PerLimb, rho = i % kP2PerLimb;
+    const uint32_t op = wv >> 1, h = wv & 1, R = rho * 2 + h;   // R: the half row's index among the limb's 32
     const ProdJob jb = jobs[limb];
     const PrimeDev *pr = &primes[jb.prime];
     const u64 q = pr->m.q, nq = pr->m.nq;
-    ctw_t ftab = (ctw_t)pr->tw.fwd;
-    u64 *my = lds + wv * PR;
-    cgptr_t row = (cgptr_t)work + (size_t)(3 * limb + wv) * PN + rho * PR;    // wave 0: operand a, wave 1: operand b
-    const uint32_t hiB = lane >> 2;
-    // A wave alone on its SIMD has nothing to hide a load's latency behind: every per-lane twiddle of the forward steps and
-    // of the first inverse step is requested BEFORE the wait for the producers (156 VGPRs; the wave may use 256), the second
-    // inverse step's once the forward step that held their registers is through.
-    ctw_t itab = (ctw_t)pr->tw.inv;
-    tw_t twB[15], tw12[4], tw13[8], itw13[8], itw12[4], itwB[15];
-    preload15(twB, ftab, 256, rho * 16 + hiB);
-#pragma unroll
-    for (int h = 0; h < 4; h++) tw12[h] = ld_tw_now(ftab + 4096 + rho * 256 + h * 64 + lane);
-#pragma unroll
-    for (int j = 0; j < 8; j++) tw13[j] = ld_tw_now(ftab + 8192 + rho * 512 + (j >> 1) * 128 + 2 * lane + (j & 1));
-    if (!wv) {
-#pragma unroll
-      for (int j = 0; j < 8; j++) itw13[j] = ld_tw_now(itab + 8192 + rho * 512 + (j >> 1) * 128 + 2 * lane + (j & 1));
-#pragma unroll
-      for (int h = 0; h < 4; h++) itw12[h] = ld_tw_now(itab + 4096 + rho * 256 + h * 64 + lane);
+    ctw_t ftab = (ctw_t)pr->tw.fwd, itab = (ctw_t)pr->tw.inv;
+    u64 *my = lds + wv * PH;
+    cgptr_t row = (cgptr_t)work + (size_t)(3 * limb + op) * PN + rho * PR;
+    // A wave alone on its SIMD has nothing to hide a load's latency behind: every per-lane twiddle is requested BEFORE the
+    // wait for the producers (the wave may use 256 VGPRs)
+    tw_t tw2[7], tw3[7], itw3[7], itw2[7];
+    preload7(tw2, ftab, 256, R * 8 + (lane >> 3));
+    preload7(tw3, ftab, 2048, R * 64 + lane);
+    if (!op) {
+      preload7(itw3, itab, 2048, R * 64 + lane);
+      preload7(itw2, itab, 256, R * 8 + (lane >> 3));
     }
     u64 v[16];
-    load_tagged(v, row, [&](int r) { return layA(lane, r); }, tag, status);
+    load_tagged(v, row, [&](int r) { return (uint32_t)(r << 6) | lane; }, tag, status);    // x = r * 64 + lane: registers = x bits 9..6
     PROD_STAMP(2);
-    constexpr int B1 = BI, B2 = bound_after4(B1), B3 = bound_after4(B2), B4 = next_bound(B3), B5 = next_bound(B4);
-    static_assert(B1 <= 16 && B2 <= 16 && B3 <= 16 && B4 <= 16 && B5 <= 16, "forward lazy range overflows");
-    fwd_radix16<true, B1>(v, TwRow{ftab, 16, rho}, q, nq);                                // stages 4..7
-    PROD_STAMP(3);
-#pragma unroll
-    for (int r = 0; r < 16; r++) my[swz(layA(lane, r))] = v[r];
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = my[swz(layB(lane, r))];
-    PROD_STAMP(4);
-    fwd_radix16<false, B2>(v, TwStepReg{twB}, q, nq);                                     // stages 8..11
-    PROD_STAMP(5);
-    if (!wv) preload15(itwB, itab, 256, rho * 16 + hiB);
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 16; r++) my[swz(layB(lane, r))] = v[r];
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = my[swz(layC(lane, r))];
-    PROD_STAMP(6);
+    constexpr int B4 = next_bound(BI), B7 = bound_after3(B4), B10 = bound_after3(B7), B13 = bound_after3(B10);
+    static_assert(!need_corr(BI) && B4 <= 16 && B7 <= 16 && B10 <= 16 && B13 <= 16, "forward lazy range overflows");
     const u64 fourq = q << 2;
+    u64 u[8];
+    {
+      const tw_t w4 = load_tw(ftab + 16 + rho);                  // stage 4: pairs (x, x + 512)
 #pragma unroll
-    for (int h = 0; h < 4; h++) {                                // stage 12: x bit 1; group e >> 2
-      const tw_t w = tw12[h];
-#pragma unroll
-      for (int j = 0; j < 2; j++) {
-        if (need_corr(B3)) v[4 * h + j] = csub_u(v[4 * h + j], q * (u64)corr_t(B3));
-        ct_bfly<false, false>(v[4 * h + j], v[4 * h + j + 2], w.w, w.wp, nq, fourq);
+      for (int j = 0; j < 8; j++) {
+        ct_bfly<true, false>(v[j], v[j + 8], w4.w, w4.wp, nq, fourq);
+        u[j] = h ? v[j + 8] : v[j];
       }
     }
+    fwd_radix8<true, B4>(u, TwRow{ftab, 32, R}, q, nq);                                   // stages 5..7: y bits 8..6
+    PROD_STAMP(3);
 #pragma unroll
-    for (int h = 0; h < 4; h++)
+    for (int r = 0; r < 8; r++) my[swh(lay1(lane, r))] = u[r];
+    wave_lds_fence();
 #pragma unroll
-      for (int j = 0; j < 2; j++) {                              // stage 13: x bit 0; group e >> 1
-        const tw_t w = tw13[2 * h + j];
-        if (need_corr(B4)) v[4 * h + 2 * j] = csub_u(v[4 * h + 2 * j], q * (u64)corr_t(B4));
-        ct_bfly<false, false>(v[4 * h + 2 * j], v[4 * h + 2 * j + 1], w.w, w.wp, nq, fourq);
-      }
+    for (int r = 0; r < 8; r++) u[r] = my[swh(lay2(lane, r))];
+    PROD_STAMP(4);
+    fwd_radix8<false, B7>(u, TwReg7{tw2}, q, nq);                                          // stages 8..10: y bits 5..3
+    PROD_STAMP(5);
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) my[swh(lay2(lane, r))] = u[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) u[r] = my[swh(lay3(lane, r))];
+    PROD_STAMP(6);
+    fwd_radix8<false, B10>(u, TwReg7{tw3}, q, nq);                                         // stages 11..13: y bits 2..0
     PROD_STAMP(7);
     const u32 kc = (u32)pr->m.kc;
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = canon_any(v[r], q, nq, kc);
-    // operand b's row crosses to the other wave (its own region: the wave is done with its exchanges, and LDS
+    for (int r = 0; r < 8; r++) u[r] = canon_any(u[r], q, nq, kc);
+    // operand b's half rows cross to operand a's waves (own region: the wave is done with its exchanges, and LDS
     // instructions of one wave execute in order)
-    if (wv) {
+    if (op) {
       wave_lds_fence();
 #pragma unroll
-      for (int r = 0; r < 16; r++) my[r * 64 + lane] = v[r];
+      for (int r = 0; r < 8; r++) my[r * 64 + lane] = u[r];
     }
     PROD_STAMP(8);
     __syncthreads();
-    if (wv) return;
-    PROD_STAMP(9);
-    const u64 mu = pr->m.mu;
+    if (!op) {
+      PROD_STAMP(9);
+      const u64 mu = pr->m.mu;
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = mulmod_lazy_2q(v[r], lds[PR + r * 64 + lane], nq, mu);   // < 2q
-    PROD_STAMP(10);
+      for (int r = 0; r < 8; r++) u[r] = mulmod_lazy_2q(u[r], lds[(wv + 2) * PH + r * 64 + lane], nq, mu);   // < 2q
+      PROD_STAMP(10);
+      inv_radix8<false>(u, TwReg7{itw3}, q, nq);                                            // stages 13..11
+      PROD_STAMP(11);
+      wave_lds_fence();
 #pragma unroll
-    for (int h = 0; h < 4; h++)
+      for (int r = 0; r < 8; r++) my[swh(lay3(lane, r))] = u[r];
+      wave_lds_fence();
 #pragma unroll
-      for (int j = 0; j < 2; j++) {
-        const tw_t w = itw13[2 * h + j];
-        gs_bfly<false>(v[4 * h + 2 * j], v[4 * h + 2 * j + 1], w.w, w.wp, nq, fourq);
-      }
+      for (int r = 0; r < 8; r++) u[r] = my[swh(lay2(lane, r))];
+      PROD_STAMP(12);
+      inv_radix8<false>(u, TwReg7{itw2}, q, nq);                                            // stages 10..8
+      PROD_STAMP(13);
+      wave_lds_fence();
 #pragma unroll
-    for (int h = 0; h < 4; h++) {
-      const tw_t w = itw12[h];
+      for (int r = 0; r < 8; r++) my[swh(lay2(lane, r))] = u[r];
+      wave_lds_fence();
 #pragma unroll
-      for (int j = 0; j < 2; j++) gs_bfly<false>(v[4 * h + j], v[4 * h + j + 2], w.w, w.wp, nq, fourq);
+      for (int r = 0; r < 8; r++) u[r] = my[swh(lay1(lane, r))];
+      inv_radix8<true>(u, TwRow{itab, 32, R}, q, nq);                                       // stages 7..5
+      PROD_STAMP(14);
+      // stage 4: the halves meet
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 8; r++) my[r * 64 + lane] = u[r];
     }
-    PROD_STAMP(11);
-    wave_lds_fence();
+    __syncthreads();                                             // (operand b's waves wait here with the others, then leave)
+    if (op) return;
+    {
+      const tw_t w4 = load_tw(itab + 16 + rho);
+      const u64 *other = lds + (wv ^ 1) * PH;
 #pragma unroll
-    for (int r = 0; r < 16; r++) my[swz(layC(lane, r))] = v[r];
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = my[swz(layB(lane, r))];
-    PROD_STAMP(12);
-    inv_radix16<false, INV_MID, false>(v, TwStepReg{itwB}, q, nq);                        // stages 11..8
-    PROD_STAMP(13);
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 16; r++) my[swz(layB(lane, r))] = v[r];
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = my[swz(layA(lane, r))];
-    PROD_STAMP(14);
-    inv_radix16<true, INV_MID, false>(v, TwRow{itab, 16, rho}, q, nq);                    // stages 7..4
+      for (int r = 0; r < 8; r++) {
+        const u64 o = other[r * 64 + lane];
+        u[r] = h ? mul_shoup_4q<true>(o + fourq - u[r], w4.w, w4.wp, nq) : csub_u(u[r] + o, fourq);   // (X, Y) -> (X + Y, (X - Y) w): < 4q
+      }
+    }
     PROD_STAMP(15);
-    gptr_t out = (gptr_t)work + (size_t)(3 * limb + 2) * PN + rho * PR;
+    gptr_t out = (gptr_t)work + (size_t)(3 * limb + 2) * PN + rho * PR + h * PH;
 #pragma unroll
-    for (int r = 0; r < 16; r++) st_handoff(out + layA(lane, r), v[r] | tag);             // < 4q (INV_MID)
+    for (int r = 0; r < 8; r++) st_handoff(out + (r << 6) + lane, u[r] | tag);            // < 4q (INV_MID)
     return;
   }
   {
     // ---- P3: inverse stages 3..0 with N^-1, 128 columns -------------------------------------------------------------------------
-    const uint32_t i = b - nP1 - nP2, limb = i / kP3PerLimb, t = (i % kP3PerLimb) * 128 + tid;
+    // The mirror of P1: a wave runs stages 3..1 on its 8 rows (8 hh + j); for stage 0 the halves meet in LDS.
+    const uint32_t i = b - nP1 - nP2, limb = i / kP3PerLimb, c = tid & 127, t = (i % kP3PerLimb) * 128 + c;
+    const uint32_t hh = uni(tid >> 7);
     const ProdJob jb = jobs[limb];
     const PrimeDev *pr = &primes[jb.prime];
     const u64 q = pr->m.q, nq = pr->m.nq;
-    cgptr_t w = (cgptr_t)work + (size_t)(3 * limb + 2) * PN + t;
-    gptr_t dst = (gptr_t)jb.d + t;
+    ctw_t itab = (ctw_t)pr->tw.inv;
+    cgptr_t w = (cgptr_t)work + (size_t)(3 * limb + 2) * PN + hh * (8 * PR) + t;
+    gptr_t dst = (gptr_t)jb.d + hh * (8 * PR) + t;
     const LastScale ls = last_scale<false>(nullptr, pr);
-    u64 v[16];
-    load_tagged(v, w, [&](int r) { return (uint32_t)r * PR; }, tag, status);
+    u64 u[8];
+    load_tagged(u, w, [&](int r) { return (uint32_t)r * PR; }, tag, status);
     PROD_STAMP(4);
-    inv_radix16<true, INV_MID, true>(v, TwRow{(ctw_t)pr->tw.inv, 1, 0}, q, nq, ls.w, ls.ni, ls.nip);
+    inv_radix8<true>(u, TwRow{itab, 2, hh}, q, nq);                                        // stages 3..1
+#pragma unroll
+    for (int j = 0; j < 8; j++) lds[hh * (8 * 128) + j * 128 + c] = u[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const u64 o = lds[(hh ^ 1) * (8 * 128) + j * 128 + c];
+      // stage 0 with the scaling folded in: (X, Y) -> ((X + Y) N^-1, (X - Y) w N^-1), each < 4q
+      u[j] = hh ? mul_shoup_4q<true>(o + (q << 2) - u[j], ls.w.w, ls.w.wp, nq) : mul_shoup_4q<true>(u[j] + o, ls.ni, ls.nip, nq);
+    }
     PROD_STAMP(2);
 #pragma unroll
-    for (int r = 0; r < 16; r++) st_stream(dst + r * PR, canon_4q(v[r], q));
+    for (int j = 0; j < 8; j++) st_stream(dst + j * PR, canon_4q(u[j], q));
     PROD_STAMP(3);
   }
 }
@@ -302,7 +374,7 @@ hipError_t poly_product_batch(hipStream_t st, const ProdJob *d_jobs, const Prime
   if (!count) return hipSuccess;
   if (count > kProdMaxLimbs) return hipErrorInvalidValue;
   const uint32_t grid = count * (2 * kP1PerOp + kP2PerLimb + kP3PerLimb);
-  hipLaunchKernelGGL(poly_product_kernel, dim3(grid), dim3(128), 0, st, d_jobs, d_primes, d_work, d_status, count, tag);
+  hipLaunchKernelGGL(poly_product_kernel, dim3(grid), dim3(kWG), 0, st, d_jobs, d_primes, d_work, d_status, count, tag);
   if (launches) ++*launches;
   return hipGetLastError();
 }

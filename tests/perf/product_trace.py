@@ -31,7 +31,8 @@ with avp.VP(spm_rows=3 * L * rows, ksk_rows=1, max_log_n=14) as vp:
     fx, fy = oracle.ntt(x, mods[0]), oracle.ntt(y, mods[0])
     prod = np.array([(int(u) * int(v)) % mods[0] for u, v in zip(fx, fy)], dtype=np.uint64)
     assert np.array_equal(vp.read(SPM, 2 * L * rows, n), oracle.intt(prod, mods[0]))
-    nwg = L * 40
+    nP1, nP2, nP3 = L * 16, L * 16, L * 8                        # workgroups of 256 threads per phase (ntt_product.hip)
+    nwg = nP1 + nP2 + nP3
     buf = np.zeros(nwg * 16, dtype=np.uint64)
     fn = vp._L.aloha_vp_debug_product_trace
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
@@ -39,13 +40,12 @@ with avp.VP(spm_rows=3 * L * rows, ksk_rows=1, max_log_n=14) as vp:
 t = buf.reshape(nwg, 16).astype(np.int64)
 t0 = t[:, 0].min()
 us = (t - t0) / 100.0                                            # 100 MHz -> microseconds
-nP1, nP2 = L * 16, L * 16
 P1 = {0: "start", 4: "operand loaded", 1: "radix-16 done", 2: "stores issued"}
-P2 = {0: "start", 2: "row loaded (all tags seen)", 3: "stages 4-7 done", 4: "exchange A->B done", 5: "stages 8-11 done",
-      6: "exchange B->C done", 7: "stages 12-13 done", 8: "canonical, b's row in LDS", 9: "barrier passed", 10: "product done",
-      11: "inverse 13-12 done", 12: "exchange C->B done", 13: "inverse 11-8 done", 14: "exchange B->A done", 15: "inverse 7-4 done"}
+P2 = {0: "start", 2: "row loaded (all tags seen)", 3: "stages 4-7 done", 4: "exchange 1->2 done", 5: "stages 8-10 done",
+      6: "exchange 2->3 done", 7: "stages 11-13 done", 8: "canonical, b's half in LDS", 9: "barrier passed", 10: "product done",
+      11: "inverse 13-11 done", 12: "exchange 3->2 done", 13: "inverse 10-8 done", 14: "exchange + inverse 7-5 done", 15: "halves met, inverse 4 done"}
 P3 = {0: "start", 4: "columns loaded (all tags seen)", 2: "radix-16 done", 3: "stores issued"}
-for name, a, steps in (("P1", us[:nP1], P1), ("P2 (operand a's wave)", us[nP1:nP1 + nP2], P2), ("P3", us[nP1 + nP2:], P3)):
+for name, a, steps in (("P1", us[:nP1], P1), ("P2 (operand a, lower half)", us[nP1:nP1 + nP2], P2), ("P3", us[nP1 + nP2:], P3)):
     print(name)
     prev = None
     for slot, what in steps.items():

@@ -13,45 +13,44 @@ LOGN, N = 14, 1 << 14
 ROWS = N // 128
 
 
-# ---- CPU: the three register layouts of a 1024-point row under the LDS swizzle (ntt_product.hip) -------------------------
-def _swz(x):
-    return x ^ ((x >> 4) & 31) ^ ((x >> 5) & 31)
+# ---- CPU: the three register layouts of a 512-point half row under the LDS swizzle (ntt_product.hip) -----------------------
+def _swh(y):
+    return y ^ ((y >> 3) & 31)
 
 
 _LAYOUTS = {
-    "A": lambda l, r: (r << 6) | l,
-    "B": lambda l, r: ((l >> 2) << 6) | (r << 2) | (l & 3),
-    "C": lambda l, r: ((r >> 2) << 8) | (l << 2) | (r & 3),
+    "1": lambda l, r: (r << 6) | l,
+    "2": lambda l, r: ((l >> 3) << 6) | (r << 3) | (l & 7),
+    "3": lambda l, r: (l << 3) | r,
 }
 
 
 @pytest.mark.parametrize("name", sorted(_LAYOUTS))
-def test_row_layouts_are_bijections_without_bank_conflicts(name):
+def test_half_row_layouts_are_bijections_without_bank_conflicts(name):
     lay = _LAYOUTS[name]
-    assert sorted(lay(l, r) for l in range(64) for r in range(16)) == list(range(1024))
-    assert sorted(_swz(x) for x in range(1024)) == list(range(1024))
-    for r in range(16):
+    assert sorted(lay(l, r) for l in range(64) for r in range(8)) == list(range(512))
+    assert sorted(_swh(y) for y in range(512)) == list(range(512))
+    for r in range(8):
         for half in range(2):                                    # a 64-bit LDS access serves 32 lanes at a time: 32 distinct 8-byte banks
-            banks = {_swz(lay(l, r)) % 32 for l in range(32 * half, 32 * half + 32)}
+            banks = {_swh(lay(l, r)) % 32 for l in range(32 * half, 32 * half + 32)}
             assert len(banks) == 32, (name, r, half)
 
 
-def test_row_layout_twiddle_indices():
+def test_half_row_twiddle_indices():
     """Stage s of the transform takes twiddle entry 2^s + (e >> (14 - s)); the kernel's per-layout index arithmetic must say the
-    same for every element a lane holds (rho = row, e = rho * 1024 + x)."""
-    for rho in (0, 5, 15):
+    same for every element a lane holds (R = half row, e = R * 512 + y; stage 4 pairs the halves of row rho = R >> 1)."""
+    for R in (0, 11, 31):
+        assert (1 << 4) + ((R * 512) >> 10) == 16 + (R >> 1)
         for l in range(64):
-            for r in range(16):
-                e = rho * 1024 + _LAYOUTS["A"](l, r)
-                for ss in range(4):                              # stages 4..7: wave-uniform, group = top ss bits of r
-                    assert (1 << (4 + ss)) + (e >> (10 - ss)) == (16 << ss) + (rho << ss) + (r >> (4 - ss))
-                e = rho * 1024 + _LAYOUTS["B"](l, r)
-                for ss in range(4):                              # stages 8..11: per lane (hiB = l >> 2)
-                    assert (1 << (8 + ss)) + (e >> (6 - ss)) == (256 << ss) + ((rho * 16 + (l >> 2)) << ss) + (r >> (4 - ss))
-                e = rho * 1024 + _LAYOUTS["C"](l, r)
-                h, rl = r >> 2, r & 3
-                assert (1 << 12) + (e >> 2) == 4096 + rho * 256 + h * 64 + l
-                assert (1 << 13) + (e >> 1) == 8192 + rho * 512 + h * 128 + 2 * l + (rl >> 1)
+            for r in range(8):
+                for ss in range(3):
+                    g = r >> (3 - ss)                            # group of sub-stage ss: the top ss bits of the register index
+                    e = R * 512 + _LAYOUTS["1"](l, r)            # stages 5..7: wave-uniform
+                    assert (1 << (5 + ss)) + (e >> (9 - ss)) == (32 << ss) + (R << ss) + g
+                    e = R * 512 + _LAYOUTS["2"](l, r)            # stages 8..10: per lane (y bits 8..6 = l >> 3)
+                    assert (1 << (8 + ss)) + (e >> (6 - ss)) == (256 << ss) + ((R * 8 + (l >> 3)) << ss) + g
+                    e = R * 512 + _LAYOUTS["3"](l, r)            # stages 11..13: per lane (y >> 3 = l)
+                    assert (1 << (11 + ss)) + (e >> (3 - ss)) == (2048 << ss) + ((R * 64 + l) << ss) + g
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
