@@ -196,3 +196,26 @@ def test_product_followed_and_preceded_by_other_work():
              "vle v0, rslt+0x0", "vfqmul.vs v2, v0, 0x3", f"vse v2, rslt+{16 * N:#x}", "break"]          # 3 * that -> rslt limb 2
     words = isa.assemble("\n".join(lines))
     run_both(words, {0: a, ROWS: b}, 6 * ROWS, (2 * ROWS, 3 * N), launches=3, repeat=2, src0=0, src1=ROWS, rslt=2 * ROWS)
+
+
+@pytest.mark.gpu
+def test_product_tags_survive_launches_of_different_sizes():
+    """The hand-off words carry a 2-bit tag per launch and a limb slot keeps the tag of the last launch that used it: products
+    of 4, 3, 2, 1 limbs leave all four tags behind, so the next 4-limb product finds no free tag and the engine wipes the
+    slots first; every result along the way (and after) equals the oracle machine."""
+    rng = np.random.default_rng(319)
+    mods = [oracle.nth_prime(LOGN, i) for i in range(4)]
+    a = np.concatenate([residues(rng, N, q) for q in mods]); b = np.concatenate([residues(rng, N, q) for q in mods])
+    with avp.VP(spm_rows=12 * ROWS, ksk_rows=1, max_log_n=LOGN) as vp:
+        o = oracle.OracleVP(spm_rows=12 * ROWS, ksk_rows=1)
+        for e in (vp, o):
+            e.write(SPM, 0, a); e.write(SPM, 4 * ROWS, b)
+        pc = 0
+        for L in (4, 3, 2, 1, 4, 4, 2, 4):
+            words = programs.assemble(programs.poly_mul(N, mods[:L]))
+            for e in (vp, o):
+                e.load_isram(pc, words)
+                assert e.run(pc, src0=0, src1=4 * ROWS, rslt=8 * ROWS) == 0
+            vp.sync()
+            assert np.array_equal(vp.read(SPM, 8 * ROWS, L * N), o.read(SPM, 8 * ROWS, L * N)), L
+            pc += 64                                             # (distinct programs: no recorded run is replayed)
