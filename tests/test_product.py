@@ -200,9 +200,10 @@ def test_product_followed_and_preceded_by_other_work():
 
 @pytest.mark.gpu
 def test_product_tags_survive_launches_of_different_sizes():
-    """The hand-off words carry a 2-bit tag per launch and a limb slot keeps the tag of the last launch that used it: products
-    of 4, 3, 2, 1 limbs leave all four tags behind, so the next 4-limb product finds no free tag and the engine wipes the
-    slots first; every result along the way (and after) equals the oracle machine."""
+    """The hand-off words carry a 2-bit tag per launch and a limb slot keeps the tag of the last launch that used it: launches
+    of different sizes can leave all four tags behind, so that a product finds no free tag and the engine wipes its
+    slots first; every result along the way (and after) equals the oracle machine.  (Sizes 1, 3, 1, 2, 1 leave tags 2, 3, 1, 0 in
+    slots 0..3 under the engine's lowest-free-tag rule: the 4-limb product that follows is the shortest sequence that wipes.)"""
     rng = np.random.default_rng(319)
     mods = [oracle.nth_prime(LOGN, i) for i in range(4)]
     a = np.concatenate([residues(rng, N, q) for q in mods]); b = np.concatenate([residues(rng, N, q) for q in mods])
@@ -211,7 +212,7 @@ def test_product_tags_survive_launches_of_different_sizes():
         for e in (vp, o):
             e.write(SPM, 0, a); e.write(SPM, 4 * ROWS, b)
         pc = 0
-        for L in (4, 3, 2, 1, 4, 4, 2, 4):
+        for L in (1, 3, 1, 2, 1, 4, 4, 2, 3, 1, 4):
             words = programs.assemble(programs.poly_mul(N, mods[:L]))
             for e in (vp, o):
                 e.load_isram(pc, words)
