@@ -220,3 +220,84 @@ def test_product_tags_survive_launches_of_different_sizes():
             vp.sync()
             assert np.array_equal(vp.read(SPM, 8 * ROWS, L * N), o.read(SPM, 8 * ROWS, L * N)), L
             pc += 64                                             # (distinct programs: no recorded run is replayed)
+
+
+def _random_product_program(rng, primes, nslots, segments):
+    """Random straight-line program at N = 2^14 whose segments are product idioms -- random registers, load order, operand and
+    destination slots (in place, squaring, shared operands), sometimes with a temporary read afterwards so that the matcher must
+    refuse -- and plain element-wise work between them (operands produced and consumed around the products)."""
+    lines = [f"vsetvl {64 * N:#x}", f"vsetq {primes[0]:#x}"]
+    defined = set()
+    slot = lambda: f"src0+{int(rng.integers(nslots)) * 8 * N:#x}"
+    for _ in range(segments):
+        kind = rng.choice(["prod", "prod", "prod", "ew", "setq", "intt"])
+        if kind == "setq":
+            lines.append(f"vsetq {int(rng.choice(primes)):#x}")
+        elif kind == "ew":
+            a, d = int(rng.integers(10)), int(rng.integers(10))
+            lines += [f"vle v{a}, {slot()}", f"{rng.choice(['vfqadd.vs', 'vfqmul.vs'])} v{d}, v{a}, {int(rng.integers(1, 1 << 59)):#x}"]
+            defined.update({a, d})
+            if rng.integers(2):
+                lines.append(f"vse v{d}, {slot()}")
+        elif kind == "intt":                                  # a transform job of the ordinary kind next to the products
+            lines += [f"vle v0, {slot()}", f"{rng.choice(['vntt', 'vintt'])} v2, v0", f"vse v2, {slot()}"]
+            defined.discard(0); defined.add(2)
+        else:
+            t1 = int(rng.integers(10))
+            t2 = int(rng.choice([r for r in range(10) if r % 2 != t1 % 2]))
+            va = int(rng.choice([r for r in range(10) if r not in (t1, t2)]))
+            vb = int(rng.choice([r for r in range(10) if r not in (t1, t2, va)]))
+            t3 = int(rng.integers(10))
+            t4 = int(rng.choice([r for r in range(10) if r != t3]))
+            sa, sb = slot(), slot()
+            if rng.integers(4) == 0:
+                sb = sa                                        # a * a
+            sd = rng.choice([slot(), sa, sb])                  # anywhere, or over an operand
+            if rng.integers(2):
+                seq = [f"vle v{va}, {sa}", f"vntt v{t1}, v{va}", f"vle v{vb}, {sb}", f"vntt v{t2}, v{vb}"]
+            else:
+                seq = [f"vle v{va}, {sa}", f"vle v{vb}, {sb}", f"vntt v{t1}, v{va}", f"vntt v{t2}, v{vb}"]
+            seq += [f"vfqmul.vv v{t3}, v{t1}, v{t2}", f"vintt v{t4}, v{t3}", f"vse v{t4}, {sd}"]
+            lines += seq
+            for ln in seq:                                     # (vs1 of a transform is undefined afterwards)
+                op, rest = ln.split(" ", 1)
+                regs = [int(x[1:]) for x in rest.replace(",", " ").split() if x[0] == "v" and x[1:].isdigit()]
+                if op in ("vntt", "vintt"):
+                    defined.discard(regs[1]); defined.add(regs[0])
+                elif op != "vse":
+                    defined.add(regs[0])
+            live = [r for r in (t1, t2, t4) if r in defined]
+            if live and rng.integers(4) == 0:                  # a temporary is read afterwards: not a product job
+                lines.append(f"vse v{int(rng.choice(live))}, {slot()}")
+    for r in sorted(defined):
+        lines.append(f"vse v{r}, src0+{(nslots + r) * 8 * N:#x}")
+    return "\n".join(lines + ["break"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_random_programs_with_products_fused_unfused_oracle(seed):
+    """Differential fuzz of the product matcher: fused engine == unfused engine == oracle machine on ALL memory, then the recorded
+    run replayed twice on other data."""
+    rng = np.random.default_rng(4000 + seed)
+    nslots = 6
+    primes = [oracle.nth_prime(LOGN, i) for i in range(3)]
+    words = isa.assemble(_random_product_program(rng, primes, nslots, 12))
+    assert len(words) < 1024
+    total = (nslots + 10) * N
+    o = oracle.OracleVP(spm_rows=(nslots + 10) * ROWS, ksk_rows=1)
+    with avp.VP(spm_rows=(nslots + 10) * ROWS, ksk_rows=1, max_log_n=LOGN) as vp, \
+            avp.VP(spm_rows=(nslots + 10) * ROWS, ksk_rows=1, max_log_n=LOGN, flags=avp.FLAG_NO_FUSION) as plain:
+        for rep in range(3):
+            mem = np.concatenate([residues(rng, N, primes[0]) for _ in range(nslots)])
+            res = []
+            for e in ((vp, plain, o) if rep == 0 else (vp, o)):
+                e.write(SPM, 0, np.zeros(total, np.uint64)); e.write(SPM, 0, mem)
+                if rep == 0:
+                    e.load_isram(0, words)
+                assert e.run(0, src0=0) == 0
+                if e is not o:
+                    e.sync()
+                res.append(e.read(SPM, 0, total))
+            for r in res[:-1]:
+                assert np.array_equal(r, res[-1]), (seed, rep)
