@@ -1,8 +1,8 @@
 """ctypes binding of the C host's key-switch (``aloha_ks_*``, include/aloha_vp.h; csrc/keyswitch_host.cpp).
 
 The C++ host generates the phase programs, owns the slot layout and issues the two exchanges as ``ncclAllGather`` on
-the engine's stream; this class only marshals arguments.  ``aloha_amd/hybrid.py`` holds the same generator in Python --
-the parity tests drive the oracle's ISA machine with it and compare the two generators word for word.
+the engine's stream; this class only marshals arguments.  It is the ONE generator: ``aloha_amd/hybrid.py`` fetches the words of every phase
+through ``program()`` below and drives the oracle's ISA machine (and the Python rehearsals of the exchanges) with them.
 """
 from __future__ import annotations
 

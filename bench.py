@@ -214,6 +214,19 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
         out["config2_ntt_n4096"] = {"single_call_us": t1 * 1e6, "batched_ntt_per_s": B / tb, "algorithmic_bytes": acc.ntt_bytes(n, B),
                                     "batched_GBps": acc.ntt_bytes(n, B) / tb / 1e9, "frac": acc.ntt_bytes(n, B) / tb / 1e9 / HBM_PEAK_GBS,
                                     "verified": ok, "cpu_port_ms": cpu_ms}
+    # ... and the reference's own ring size, N = 2^13 (every tv/ vector, every shipped program): batched forward transforms
+    logn, n, B = 13, 1 << 13, 4096
+    q = avp.nth_prime(logn, 0)
+    with avp.VP(spm_rows=B * n // 128, ksk_rows=1, max_log_n=13, device=device) as vp:
+        vp.fill_synthetic(SPM, 0, logn, [q] * 2, seed_base=0xA10A + 200000)
+        x = vp.read(SPM, 0, n)
+        vp.ntt_rows(SPM, n // 128, 0, logn, [q])
+        ok = bool(np.array_equal(vp.read(SPM, n // 128, n), oracle.ntt(x, q)))
+        tb = timeit(lambda: vp.ntt_rows(SPM, 0, 0, logn, [q] * B), vp.sync, 30)
+        out["reference_size_ntt_n8192"] = {"batched_ntt_per_s": B / tb, "algorithmic_bytes": acc.ntt_bytes(n, B), "batched_GBps": acc.ntt_bytes(n, B) / tb / 1e9,
+                                            "frac": acc.ntt_bytes(n, B) / tb / 1e9 / HBM_PEAK_GBS, "verified": ok,
+                                            "reference_rtl_derived_ntt_per_s": 1e8 / 850,
+                                            "note": "the RTL's figure is DERIVED, not measured: 832 + 18 cycles per transform (ntt_fsm.sv:68, vp_defines.vh:79-81) at the test bench's 100 MHz"}
     # -- config 3: 8-limb polynomial product at N = 2^14 ------------------------------------------------------------------
     logn, n, L = 14, 1 << 14, 8
     rows = n // 128
