@@ -191,12 +191,20 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
     SPM, KSK = 0, 1
 
     def timeit(fn, sync, reps):
+        # median of up to five blocks of back-to-back calls: the host side of this stack now and then pauses for 20-80 ms
+        # between two launches (seen as GAPS in rocprofv3 traces, never as long kernels: profiles/r03_z_launch_gaps.txt), and
+        # one such pause inside a single long loop is the whole figure for a 15 us operation
         fn(); sync()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        sync()
-        return (time.perf_counter() - t0) / reps
+        nblk = 5 if reps >= 50 else 3 if reps >= 15 else 1
+        per = max(1, reps // nblk)
+        ts = []
+        for _ in range(nblk):
+            t0 = time.perf_counter()
+            for _ in range(per):
+                fn()
+            sync()
+            ts.append((time.perf_counter() - t0) / per)
+        return sorted(ts)[len(ts) // 2]
 
     # -- config 2: one forward NTT at N = 2^12 (latency), and batched -----------------------------------------------------
     logn, n = 12, 1 << 12

@@ -26,12 +26,19 @@ SPM, KSK = 0, 1
 
 
 def timeit(fn, sync, reps):
+    # median of up to five blocks of back-to-back calls (rare 20-80 ms pauses of the host between two launches would
+    # otherwise be the whole figure of a short operation: profiles/r03_z_launch_gaps.txt)
     fn(); sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    sync()
-    return (time.perf_counter() - t0) / reps
+    nblk = 5 if reps >= 50 else 3 if reps >= 15 else 1
+    per = max(1, reps // nblk)
+    ts = []
+    for _ in range(nblk):
+        t0 = time.perf_counter()
+        for _ in range(per):
+            fn()
+        sync()
+        ts.append((time.perf_counter() - t0) / per)
+    return sorted(ts)[len(ts) // 2]
 
 
 def config2():
