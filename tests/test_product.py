@@ -301,3 +301,29 @@ def test_random_programs_with_products_fused_unfused_oracle(seed):
                 res.append(e.read(SPM, 0, total))
             for r in res[:-1]:
                 assert np.array_equal(r, res[-1]), (seed, rep)
+
+
+@pytest.mark.gpu
+def test_products_of_two_engines_interleaved():
+    """Two handles (two streams, two scratch buffers) launch their products alternately without waiting for each other: the
+    waits inside one launch must not depend on what else runs on the chip."""
+    L = 8
+    mods = [oracle.nth_prime(LOGN, i) for i in range(L)]
+    rng = np.random.default_rng(320)
+    words = programs.assemble(programs.poly_mul(N, mods))
+    data = []
+    for _ in range(2):
+        a = np.concatenate([residues(rng, N, q) for q in mods]); b = np.concatenate([residues(rng, N, q) for q in mods])
+        o = oracle.OracleVP(spm_rows=3 * L * ROWS, ksk_rows=1)
+        o.write(SPM, 0, a); o.write(SPM, L * ROWS, b); o.load_isram(0, words)
+        assert o.run(0, src0=0, src1=L * ROWS, rslt=2 * L * ROWS) == 0
+        data.append((a, b, o.read(SPM, 2 * L * ROWS, L * N)))
+    with avp.VP(spm_rows=3 * L * ROWS, ksk_rows=1, max_log_n=LOGN) as v0, avp.VP(spm_rows=3 * L * ROWS, ksk_rows=1, max_log_n=LOGN) as v1:
+        for vp, (a, b, _) in zip((v0, v1), data):
+            vp.write(SPM, 0, a); vp.write(SPM, L * ROWS, b); vp.load_isram(0, words)
+        for _ in range(50):
+            for vp in (v0, v1):
+                assert vp.run(0, src0=0, src1=L * ROWS, rslt=2 * L * ROWS) == 0
+        for vp, (_, _, want) in zip((v0, v1), data):
+            vp.sync()
+            assert np.array_equal(vp.read(SPM, 2 * L * ROWS, L * N), want)
