@@ -191,9 +191,10 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
     SPM, KSK = 0, 1
 
     def timeit(fn, sync, reps):
-        # median of up to five blocks of back-to-back calls: the host side of this stack now and then pauses for 20-80 ms
-        # between two launches (seen as GAPS in rocprofv3 traces, never as long kernels: profiles/r03_z_launch_gaps.txt), and
-        # one such pause inside a single long loop is the whole figure for a 15 us operation
+        # median of up to five blocks of back-to-back calls: a process that overdraws the container's CPU quota is paused by the kernel
+        # for 20-80 ms (seen as GAPS between launches in rocprofv3 traces, never as long kernels; the cause found in round 3 -- the
+        # oracle's idle OpenMP workers spinning -- is fixed, profiles/r03_z_launch_gaps.txt), and one such pause inside a single
+        # long loop is the whole figure for a 15 us operation
         fn(); sync()
         nblk = 5 if reps >= 50 else 3 if reps >= 15 else 1          # (one synchronisation per block: ~20 us spread over its calls)
         per = max(1, reps // nblk)
@@ -681,9 +682,9 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The timed region: EXACTLY K steps between barriers.  The host side of this stack now and then pauses for 20-80 ms between
-    # two launches (gaps in rocprofv3 traces, never long kernels: profiles/r03_z_launch_gaps.txt); with K = 20 such a pause is
-    # longer than the whole region.  It shows as wall time far above the device time of the same K steps (HIP events on the
+    # The timed region: EXACTLY K steps between barriers.  A process that overdraws the container's CPU quota is paused by the
+    # kernel for 20-80 ms (gaps between launches in rocprofv3 traces, never long kernels; profiles/r03_z_launch_gaps.txt: the cause
+    # found in round 3, the oracle's spinning OpenMP workers, is fixed); with K = 20 such a pause is longer than the whole region.  It shows as wall time far above the device time of the same K steps (HIP events on the
     # engine's stream); such an attempt is repeated (at most twice) and reported in `discarded_attempts`.
     discarded = []
     for attempt in range(3):

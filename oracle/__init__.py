@@ -43,6 +43,10 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build()
+        # idle OpenMP workers must sleep, not spin: a team of one-per-logical-CPU threads spinning behind a one-limb ``ntt`` call
+        # burns the container's CPU quota and the kernel then throttles the WHOLE process for tens of milliseconds -- seen as
+        # 20-80 ms pauses between GPU launches in whatever is timed next (profiles/r03_z_launch_gaps.txt)
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = C.CDLL(_SO)
         u64, u32, p = C.c_uint64, C.c_uint32, C.c_void_p
         L.orc_mulmod.restype = u64; L.orc_mulmod.argtypes = [u64, u64, u64]
@@ -63,6 +67,7 @@ def lib() -> C.CDLL:
         L.orc_vautn.restype = None; L.orc_vautn.argtypes = [p, p, C.c_uint, u64]
         L.orc_vautz.restype = None; L.orc_vautz.argtypes = [p, p, C.c_uint, u64, u64]
         L.orc_set_threads.restype = C.c_int; L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads(1)                                     # one thread unless a caller asks for more (set_threads)
         L.orc_vroli.restype = None; L.orc_vroli.argtypes = [p, p, C.c_uint, u64]
         L.orc_ntt_batch.restype = C.c_int; L.orc_ntt_batch.argtypes = [p, C.c_uint, u64, C.c_uint, C.c_int]
         L.orc_vp_create.restype = p; L.orc_vp_create.argtypes = [u64, u64]

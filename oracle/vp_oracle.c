@@ -330,7 +330,7 @@ int orc_ntt_batch(uint64_t *a, unsigned logn, uint64_t q, unsigned count, int in
   else orc_make_tables(q, psi, logn, tab, NULL);
   /* limbs are independent: the CPU baseline of bench.py runs this loop on all host cores (OpenMP,
    * OMP_NUM_THREADS); one thread gives the scalar-port figure */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (count > 1)
   for (unsigned c = 0; c < count; c++) {
     if (inverse) orc_intt(a + (size_t)c * n, logn, q, tab);
     else orc_ntt(a + (size_t)c * n, logn, q, tab);
