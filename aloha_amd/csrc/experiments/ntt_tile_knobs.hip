@@ -101,7 +101,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t limb_rsrc(const u64 *p) {
 }
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int AUX_SC1 = 16;          // cache-policy operand of the gfx940+ buffer builtins: bit 4 = sc1
-__device__ __forceinline__ u64 ld_handoff(cgptr_t p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // global_load_dwordx2 ... sc1
+// (ld_handoff: ntt_device.hpp)
 
 // ---- column pass (N = 2^16): 16 adjacent columns x 256 rows per workgroup ---------------------
 // A mapping: thread (col = tid & 15, pl = tid >> 4) holds rows pl + 16k   (stages 0..3)
@@ -533,7 +533,7 @@ constexpr uint32_t kFusedStats = kFusedShards * 32;                       // [0]
 constexpr uint32_t kFusedDone = (kFusedShards + 1) * 32;                  // first arrival counter
 constexpr uint32_t kTicketExit = 0xfffffffeu, kTicketSkip = 0xffffffffu;
 
-typedef __attribute__((address_space(1))) uint32_t *gu32_t;
+// (gu32_t: ntt_device.hpp)
 __device__ __forceinline__ uint32_t ld_u32_sc1(gu32_t p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Signalling a column tile without a store-drain stall.  vmcnt decrements in issue order on gfx9-class targets

@@ -42,6 +42,18 @@ __device__ __forceinline__ void st_stream(gptr_t p, u64 x) {
 #endif
 }
 
+// two adjacent words (16-byte aligned) as ONE 16-byte store
+typedef u64 u64x2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_stream2(gptr_t p, u64 x, u64 y) {
+  u64x2v_t v = {x, y};
+  typedef ALOHA_AS_GLOBAL u64x2v_t *gv2_t;
+#if ALOHA_NT
+  __builtin_nontemporal_store(v, (gv2_t)p);
+#else
+  *(gv2_t)p = v;
+#endif
+}
+
 // uniform (SGPR) value from a value the compiler cannot prove wave-uniform
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -301,6 +313,122 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ u64 scale_canon(u64 x, u64 ni, u64 nip, u64 q, u64 nq) {
   const u64 r = mul_shoup_4q<true>(x, ni, nip, nq);          // < 4q
   return csub_u(csub_u(r, q << 1), q);
+}
+
+// ---- hand-off between workgroups of ONE launch by tagged words (ntt_product.hip): every handed-over 8-byte word is < 2^62 and
+// carries the launch's 2-bit tag in its top bits, written by one sc1 (write-through) store; the consumer sweeps with sc1 loads
+// until every word shows the tag
+constexpr uint32_t kSpinLimit = 1u << 15;                    // sweeps before a wait gives up (~30 ms)
+constexpr u64 kTagMask = 3ull << 62;
+
+typedef ALOHA_AS_GLOBAL uint32_t *gu32_t;
+__device__ __forceinline__ u64 ld_handoff(cgptr_t p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }       // global_load_dwordx2 sc1
+__device__ __forceinline__ void st_handoff(gptr_t p, u64 x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }    // global_store_dwordx2 sc1
+
+// ---- radix-8 register steps on 512-point regions (ntt_product.hip; the radix-8 single-pass kernel of ntt_single.hip) --------------
+// A half row (512 points, 8 per lane) in LDS: word y ^ ((y >> 3) & 31) -- a bijection under which the three layouts below
+// touch 32 distinct 8-byte banks per half-wave (checked exhaustively on the host, tests/test_product.py); register r of
+// lane l holds y =
+__device__ __forceinline__ uint32_t swh(uint32_t y) { return y ^ ((y >> 3) & 31); }
+__device__ __forceinline__ uint32_t lay1(uint32_t l, uint32_t r) { return (r << 6) | l; }                               // registers = bits 8..6
+__device__ __forceinline__ uint32_t lay2(uint32_t l, uint32_t r) { return ((l >> 3) << 6) | (r << 3) | (l & 7); }      // registers = bits 5..3
+__device__ __forceinline__ uint32_t lay3(uint32_t l, uint32_t r) { return (l << 3) | r; }                              // registers = bits 2..0
+
+struct TwRow {                     // entries 2^(S0+ss) + a*2^ss + g of the plain (w, w') table
+  ctw_t tab;
+  uint32_t base, a;
+  __device__ __forceinline__ tw_t operator()(int ss, int g) const { return load_tw(tab + (base << ss) + (a << ss) + g); }
+};
+
+// per-lane twiddles as ordinary global loads (they keep their program order): issued where the code says, not at their use
+__device__ __forceinline__ tw_t ld_tw_now(ctw_t p) {
+  const gtw_t g = (gtw_t)p;
+  tw_t t;
+  t.w = g->w;
+  t.wp = g->wp;
+  return t;
+}
+__device__ __forceinline__ void preload15(tw_t (&t)[15], ctw_t tab, uint32_t base, uint32_t a) {
+#pragma unroll
+  for (int ss = 0; ss < 4; ss++)
+#pragma unroll
+    for (int g = 0; g < (1 << ss); g++) t[(1 << ss) - 1 + g] = ld_tw_now(tab + (base << ss) + (a << ss) + g);
+}
+
+__device__ __forceinline__ void preload7(tw_t (&t)[7], ctw_t tab, uint32_t base, uint32_t a) {
+#pragma unroll
+  for (int ss = 0; ss < 3; ss++)
+#pragma unroll
+    for (int g = 0; g < (1 << ss); g++) t[(1 << ss) - 1 + g] = ld_tw_now(tab + (base << ss) + (a << ss) + g);
+}
+struct TwReg7 {                    // the 7 twiddles of a radix-8 step from registers: index 2^ss - 1 + g
+  const tw_t (&r)[7];
+  __device__ __forceinline__ tw_t operator()(int ss, int g) const { return r[(1 << ss) - 1 + g]; }
+};
+
+// radix-8 register steps: sub-stage ss pairs v[i] with v[i + (4 >> ss)], group g of sub-stage ss takes tw(ss, g) -- the
+// radix-16 steps of ntt_device.hpp with three sub-stages.  Forward: relaxed butterflies on the lazy-range plan (BIN -> bound_after3(BIN));
+// inverse: Gentleman-Sande butterflies, every value < 4q before and after.
+constexpr int bound_after3(int b) { return next_bound(next_bound(next_bound(b))); }
+template <bool UNI, int BIN, typename TW>
+__device__ __forceinline__ void fwd_radix8(u64 (&v)[8], const TW &tw, u64 q, u64 nq) {
+  constexpr int B[3] = {BIN, next_bound(BIN), next_bound(next_bound(BIN))};
+  const u64 fourq = q << 2;
+#pragma unroll
+  for (int ss = 0; ss < 3; ss++) {
+    const int half = 4 >> ss;
+#pragma unroll
+    for (int g = 0; g < (1 << ss); g++) {
+      const tw_t t = tw(ss, g);
+#pragma unroll
+      for (int jj = 0; jj < half; jj++) {
+        const int i0 = g * 2 * half + jj;
+        if (need_corr(B[ss])) v[i0] = csub_u(v[i0], q * (u64)corr_t(B[ss]));
+        ct_bfly<UNI, false>(v[i0], v[i0 + half], t.w, t.wp, nq, fourq);
+      }
+    }
+  }
+}
+template <bool UNI, typename TW>
+__device__ __forceinline__ void inv_radix8(u64 (&v)[8], const TW &tw, u64 q, u64 nq) {
+  const u64 fourq = q << 2;
+#pragma unroll
+  for (int idx = 0; idx < 3; idx++) {
+    const int ss = 2 - idx, half = 4 >> ss;
+#pragma unroll
+    for (int g = 0; g < (1 << ss); g++) {
+      const tw_t t = tw(ss, g);
+#pragma unroll
+      for (int jj = 0; jj < half; jj++) {
+        const int i0 = g * 2 * half + jj;
+        gs_bfly<UNI>(v[i0], v[i0 + half], t.w, t.wp, nq, fourq);
+      }
+    }
+  }
+}
+
+// the wave's NV x 64 tagged words at p + off(r): swept with sc1 loads until every word of every lane carries `tag`
+// (bits 63..62); returns them with the tag removed
+template <int NV, class OFF>
+__device__ __forceinline__ void load_tagged(u64 (&v)[NV], cgptr_t p, const OFF &off, u64 tag, gu32_t status) {
+  uint32_t sweeps = 0;
+  for (;;) {
+    u64 bad = 0;
+#pragma unroll
+    for (int r = 0; r < NV; r++) {
+      v[r] = ld_handoff(p + off(r));
+      bad |= v[r] ^ tag;
+    }
+    if (__builtin_amdgcn_ballot_w64((bad & kTagMask) != 0) == 0) break;
+    if (++sweeps > kSpinLimit) {                                 // (cannot happen in a correct schedule: reported, not hung on)
+      if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+        __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int r = 0; r < NV; r++) v[r] &= ~kTagMask;
 }
 
 // Intermediate formats between the passes of one transform:

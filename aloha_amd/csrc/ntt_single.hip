@@ -28,6 +28,7 @@
 // (vector loads, 16 B per lane).  The inverse runs the same steps backwards with the
 // Gentleman-Sande butterflies and fuses N^-1 into the last one.
 #include <atomic>
+#include <cstdlib>
 
 #include "kernels.hpp"
 #include "modarith.hpp"
@@ -170,8 +171,13 @@ __global__ __launch_bounds__((1 << LOGN) / 16) __attribute__((amdgpu_waves_per_e
         }
     }
     const u32 kc = (u32)pr->m.kc;
+    if (E == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) st_stream(dst + lay3<LOGN>(t, r), canon_any(v[r], q, nq, kc));
+      for (int r = 0; r < 16; r++) st_stream(dst + lay3<LOGN>(t, r), canon_any(v[r], q, nq, kc));
+    } else {                                                     // a lane's 2^E adjacent words leave as 16-byte stores
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) st_stream2(dst + lay3<LOGN>(t, r), canon_any(v[r], q, nq, kc), canon_any(v[r + 1], q, nq, kc));
+    }
   } else {
     const u64 fourq = q << 2;
 #pragma unroll
@@ -212,6 +218,127 @@ __global__ __launch_bounds__((1 << LOGN) / 16) __attribute__((amdgpu_waves_per_e
   }
 }
 
+
+// ---- N = 2^12 with EIGHT values per thread ---------------------------------------------------------------------------------------
+// The kernel above keeps 16 values per thread: 121 VGPRs, four waves per SIMD.  Here a limb is 512 threads x 8 values and the
+// twelve stages are four radix-8 register steps (ntt_device.hpp):
+//     L0  registers = index bits 11..9    e = r * 512 + t               loads (coalesced 8 B lanes), wave-uniform twiddles
+//     L1  registers = bits 8..6           e = w * 512 + r * 64 + l      (w = wave, l = lane) wave-uniform twiddles
+//     L2  registers = bits 5..3           e = w * 512 + (l >> 3) * 64 + r * 8 + (l & 7)
+//     L3  registers = bits 2..0           e = w * 512 + l * 8 + r       stores (64 B per lane)
+// After L0 a wave owns the 512 elements with its three top bits: ONE workgroup barrier, the other two exchanges are wave-private
+// (lay1..lay3 and the swizzle of ntt_device.hpp inside the wave's region); loads and stores are lane-contiguous (a last / first
+// wave-private transpose: a lane's own 8 words stored directly are 64 partial lines per instruction, half the kernel's speed).
+// 64-72 VGPRs: six to eight waves per SIMD, three or four workgroups per CU.  Jobs with a folded scalar (LimbJob::sc) keep the
+// sixteen-value kernel.
+template <bool INV>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) void ntt_single8_kernel(const LimbJob *__restrict__ jobs, const PrimeDev *__restrict__ primes) {
+  constexpr int N = 4096, T = 512;
+  __shared__ u64 lds[N];
+  const uint32_t t = threadIdx.x, l = t & 63, w = uni(t >> 6);
+  const LimbJob jb = jobs[blockIdx.x];
+  const PrimeDev *pr = &primes[jb.prime];
+  const u64 q = pr->m.q, nq = pr->m.nq;
+  ctw_t tab = (ctw_t)(INV ? pr->tw.inv : pr->tw.fwd);
+  cgptr_t src = (cgptr_t)jb.src;
+  gptr_t dst = (gptr_t)jb.dst;
+  u64 *my = lds + w * 512;
+  u64 v[8];
+  if (!INV) {
+    constexpr int B0 = FWD_IN, B1 = bound_after3(B0), B2 = bound_after3(B1), B3 = bound_after3(B2), B4 = bound_after3(B3);
+    static_assert(B1 <= 16 && B2 <= 16 && B3 <= 16 && B4 <= 16, "forward lazy range overflows");
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = ld_stream(src + r * T + t);
+    tw_t tw2[7];
+    preload7(tw2, tab, 64, w * 8 + (l >> 3));
+    fwd_radix8<true, B0>(v, TwRow{tab, 1, 0}, q, nq);                                    // stages 0..2
+#pragma unroll
+    for (int r = 0; r < 8; r++) lds[r * 512 + swh(t)] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = my[swh(lay1(l, r))];
+    fwd_radix8<true, B1>(v, TwRow{tab, 8, w}, q, nq);                                    // stages 3..5
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) my[swh(lay1(l, r))] = v[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = my[swh(lay2(l, r))];
+    fwd_radix8<false, B2>(v, TwReg7{tw2}, q, nq);                                        // stages 6..8
+    tw_t tw3[7];                                                 // (requested only now: with tw2 alive as well the kernel spills at 80 VGPRs)
+    preload7(tw3, tab, 512, w * 64 + l);
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) my[swh(lay2(l, r))] = v[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = my[swh(lay3(l, r))];
+    fwd_radix8<false, B3>(v, TwReg7{tw3}, q, nq);                                        // stages 9..11
+    const u32 kc = (u32)pr->m.kc;
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = canon_any(v[r], q, nq, kc);
+    // back to lane-contiguous words for the stores (a lane's own 8 words are 64 B apart from its neighbour's: as stores that is
+    // 64 partial lines per instruction -- measured at HALF the kernel's speed)
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) my[swh(lay3(l, r))] = v[r];
+    wave_lds_fence();
+    gptr_t o = dst + w * 512 + l;
+#pragma unroll
+    for (int r = 0; r < 8; r++) st_stream(o + r * 64, my[swh(lay1(l, r))]);
+  } else {
+    tw_t tw3[7], tw2[7];
+    preload7(tw3, tab, 512, w * 64 + l);
+    cgptr_t i = src + w * 512 + l;
+#pragma unroll
+    for (int r = 0; r < 8; r++) my[swh(lay1(l, r))] = ld_stream(i + r * 64);               // < 2^60 < 4q; lane-contiguous loads
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = my[swh(lay3(l, r))];
+    wave_lds_fence();
+    preload7(tw2, tab, 64, w * 8 + (l >> 3));
+    inv_radix8<false>(v, TwReg7{tw3}, q, nq);                                              // stages 11..9
+#pragma unroll
+    for (int r = 0; r < 8; r++) my[swh(lay3(l, r))] = v[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = my[swh(lay2(l, r))];
+    inv_radix8<false>(v, TwReg7{tw2}, q, nq);                                              // stages 8..6
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) my[swh(lay2(l, r))] = v[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = my[swh(lay1(l, r))];
+    inv_radix8<true>(v, TwRow{tab, 8, w}, q, nq);                                          // stages 5..3
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) my[swh(lay1(l, r))] = v[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = lds[r * 512 + swh(t)];
+    // stages 2, 1 as plain Gentleman-Sande butterflies, stage 0 with N^-1 folded into its two products
+    const u64 fourq = q << 2;
+    {
+      const tw_t a = load_tw(tab + 4), b = load_tw(tab + 5), c = load_tw(tab + 6), d = load_tw(tab + 7);
+      gs_bfly<true>(v[0], v[1], a.w, a.wp, nq, fourq); gs_bfly<true>(v[2], v[3], b.w, b.wp, nq, fourq);
+      gs_bfly<true>(v[4], v[5], c.w, c.wp, nq, fourq); gs_bfly<true>(v[6], v[7], d.w, d.wp, nq, fourq);
+      const tw_t e = load_tw(tab + 2), f = load_tw(tab + 3);
+      gs_bfly<true>(v[0], v[2], e.w, e.wp, nq, fourq); gs_bfly<true>(v[1], v[3], e.w, e.wp, nq, fourq);
+      gs_bfly<true>(v[4], v[6], f.w, f.wp, nq, fourq); gs_bfly<true>(v[5], v[7], f.w, f.wp, nq, fourq);
+    }
+    const LastScale ls = last_scale<false>(nullptr, pr);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const u64 x = v[j], y = v[j + 4];
+      v[j] = mul_shoup_4q<true>(x + y, ls.ni, ls.nip, nq);
+      v[j + 4] = mul_shoup_4q<true>(x + fourq - y, ls.w.w, ls.w.wp, nq);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) st_stream(dst + r * T + t, canon_4q(v[r], q));
+  }
+}
+
 template <int LOGN, bool INV, bool SC = false>
 hipError_t launch_single(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count) {
   constexpr int N = 1 << LOGN;
@@ -246,6 +373,15 @@ hipError_t ntt_single_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDe
     }
     if (launches) ++*launches;
     return e;
+  }
+  // N = 2^12: eight values per thread (43.5-43.9 M forward / 43.4-43.8 M inverse NTT/s against 41.3-41.7 / 42.0 for sixteen,
+  // 8192 limbs of 16 primes, profiles/r03_small_n_radix8.txt); ALOHA_SINGLE16=1 selects the sixteen-value kernel (A/B timing)
+  static const bool eight = getenv("ALOHA_SINGLE16") == nullptr;
+  if (eight && logn == 12) {
+    if (inverse) hipLaunchKernelGGL((ntt_single8_kernel<true>), dim3(count), dim3(512), 0, st, d_jobs, d_primes);
+    else hipLaunchKernelGGL((ntt_single8_kernel<false>), dim3(count), dim3(512), 0, st, d_jobs, d_primes);
+    if (launches) ++*launches;
+    return hipGetLastError();
   }
   switch (logn * 2 + (inverse ? 1 : 0)) {
     case 24: e = launch_single<12, false>(st, d_jobs, d_primes, count); break;
