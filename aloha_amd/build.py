@@ -38,16 +38,17 @@ def _newest(paths) -> float:
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build_variant(name: str, defines=(), force: bool = True) -> str:
+def build_variant(name: str, defines=(), force: bool = True, experiments: bool = True) -> str:
     """A/B variant of the library with extra -D macros -> lib/libaloha_vp_<name>.so (select it with
-    ALOHA_VP_LIB=...; bench.py then skips its oracle guard, variants may compute garbage on purpose)."""
+    ALOHA_VP_LIB=...; bench.py then skips its oracle guard, variants may compute garbage on purpose).
+    ``experiments=False``: the DEFAULT sources with the extra macros (A/B of a knob of the shipped kernels, e.g. ALOHA_ROW_BMAP)."""
     out = os.path.join(LIBDIR, f"libaloha_vp_{name}.so")
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in VARIANT_SOURCES]
+    srcs = [os.path.join(CSRC, s) for s in (VARIANT_SOURCES if experiments else SOURCES)]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest(deps):
         return out
-    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-DALOHA_EXPERIMENTS=1"] + \
+    cmd = [hipcc(), "-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}"] + (["-DALOHA_EXPERIMENTS=1"] if experiments else []) + \
           [f"-D{d}" for d in defines if d] + ["-o", out] + srcs + ["-Wl,-rpath,/opt/rocm/lib", "-ldl"]
     subprocess.check_call(cmd)
     return out
@@ -89,3 +90,6 @@ if __name__ == "__main__":
         if a.startswith("--variant="):                      # --variant=name:MACRO=1,MACRO2=0
             name, _, defs = a.split("=", 1)[1].partition(":")
             print(build_variant(name, defs.split(",")))
+        if a.startswith("--plain="):                        # --plain=name:MACRO=1  (the default sources + macros)
+            name, _, defs = a.split("=", 1)[1].partition(":")
+            print(build_variant(name, defs.split(","), experiments=False))

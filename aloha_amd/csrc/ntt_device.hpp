@@ -318,7 +318,8 @@ __device__ __forceinline__ u64 scale_canon(u64 x, u64 ni, u64 nip, u64 q, u64 nq
 // ---- hand-off between workgroups of ONE launch by tagged words (ntt_product.hip): every handed-over 8-byte word is < 2^62 and
 // carries the launch's 2-bit tag in its top bits, written by one sc1 (write-through) store; the consumer sweeps with sc1 loads
 // until every word shows the tag
-constexpr uint32_t kSpinLimit = 1u << 15;                    // sweeps before a wait gives up (~30 ms)
+constexpr long long kWaitTicks = 100000000ll;               // a wait gives up after 1 s of wall_clock64 (100 MHz constant-rate counter): a bound in
+                                                             // TIME -- a count of sweeps is a different time on a busy chip than on an idle one
 constexpr u64 kTagMask = 3ull << 62;
 
 typedef ALOHA_AS_GLOBAL uint32_t *gu32_t;
@@ -411,8 +412,8 @@ __device__ __forceinline__ void inv_radix8(u64 (&v)[8], const TW &tw, u64 q, u64
 // (bits 63..62); returns them with the tag removed
 template <int NV, class OFF>
 __device__ __forceinline__ void load_tagged(u64 (&v)[NV], cgptr_t p, const OFF &off, u64 tag, gu32_t status) {
-  uint32_t sweeps = 0;
-  for (;;) {
+  long long t0 = 0;
+  for (uint32_t sweeps = 0;; sweeps++) {
     u64 bad = 0;
 #pragma unroll
     for (int r = 0; r < NV; r++) {
@@ -420,10 +421,14 @@ __device__ __forceinline__ void load_tagged(u64 (&v)[NV], cgptr_t p, const OFF &
       bad |= v[r] ^ tag;
     }
     if (__builtin_amdgcn_ballot_w64((bad & kTagMask) != 0) == 0) break;
-    if (++sweeps > kSpinLimit) {                                 // (cannot happen in a correct schedule: reported, not hung on)
-      if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
-        __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
+    if ((sweeps & 63) == 0) {                                    // (the clock is read on the first sweep that fails and every 64th after it)
+      const long long now = wall_clock64();
+      if (!sweeps) t0 = now;
+      else if (now - t0 > kWaitTicks) {                          // (cannot happen while every XCD dispatches in order: reported, not hung on)
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)
+          __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
     }
     __builtin_amdgcn_s_sleep(1);
   }

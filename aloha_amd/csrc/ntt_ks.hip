@@ -188,6 +188,9 @@ __device__ __forceinline__ void products_chunk(const u64 (&v)[16], int m, cgptr_
   }
 }
 
+// (Round 4, measured and dropped: touching the lines of a tile's key rows -- one dword per 128-byte line and lane, between the two
+// radix-16 steps of the tile's transform -- so that the products' loads find them in L2 / the Infinity Cache: HMult 0.283 against
+// 0.272 ms, rotate 0.401 against 0.393: the extra requests cost more than the latency they hide, profiles/r04_row_lds_layout_ab.txt.)
 // S waves per workgroup share the digits of one (group, R rows): each takes a contiguous share of the blocks, wave 0 adds the
 // accumulators of the others (through LDS) and stores.  A wave's chain of tiles is serial -- load, transform, load the
 // key, multiply -- and a key-switch has few groups, so at S = 1 the kernel's time was one wave's latency (the same ~100 us for
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(R == 2 ?
   constexpr int PRE = R == 2 ? 0 : 3;                            // second-step twiddles issued early (registers against latency)
   constexpr uint32_t WPG = 256 / R;                              // workgroups per group
   __shared__ u64 lds_all[S * 4 * RP];
+  static_assert(S == 1 || R * 8 * 64 <= 4 * RP, "the cross-wave reduction writes R*4*2*64 words into a wave's transpose region");
   const uint32_t wv = S > 1 ? uni(threadIdx.x >> 6) : 0;
   u64 *lds = lds_all + wv * 4 * RP;
   const RowDotGroup *g = &groups[blockIdx.x / WPG];

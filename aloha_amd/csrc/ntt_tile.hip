@@ -242,10 +242,15 @@ __device__ __forceinline__ void row_tile(u64 *lds, const LimbJob *__restrict__ j
   for (int kk = 0; kk < 16; kk++) st_stream(&dst[16 * kk], v[kk]);
 }
 
-// (the inverse instantiations settle at 106-110 VGPRs, 4 waves per SIMD; holding them to 96 costs 28 B of scratch and 2 %)
-// The forward bundle tiles are held to the register budget of 5 waves per SIMD (96 VGPRs; they need 94-98).
+// (the inverse instantiations settle at 100-134 VGPRs, 3-4 waves per SIMD; holding them to 96 costs 28 B of scratch and 2 %)
+// The forward bundle tiles need 94-98 VGPRs by layout: 96 (5 waves per SIMD) as shipped.  Two registers more cost a fifth of
+// the occupancy and 1 % of the headline; FORCING 96 (ALOHA_ROW_FWD_WAVES = 5) where the allocation wants 98 costs 20 B of scratch and
+// 3 % (profiles/r04_row_lds_layout_ab.txt).
+#ifndef ALOHA_ROW_FWD_WAVES
+#define ALOHA_ROW_FWD_WAVES 1
+#endif
 template <bool INV, bool UNIA, bool FIRST, bool LAST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void ntt_row_kernel(const LimbJob *__restrict__ jobs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!INV && UNIA) ? ALOHA_ROW_FWD_WAVES : 1))) void ntt_row_kernel(const LimbJob *__restrict__ jobs,
                                                                                               const PrimeDev *__restrict__ primes,
                                                                                               const TileDesc *__restrict__ tiles) {
   __shared__ u64 sdata[4 * RP];

@@ -13,12 +13,30 @@ namespace {
 constexpr int LINES = 16;          // lines per column tile
 constexpr int PITCH = 257;         // column-tile LDS pitch in words: odd => conflict-free 64-bit accesses; 32896 B, 4 workgroups per CU
 constexpr int TW_BLK = 256;        // twiddle entries per block
-// Row pass: LDS slot of point p of wave-line lw is lw*RP + p + (p >> 4); RP = 280 (== 24 mod 32) makes the B-mapping
-// 64-bit reads conflict-free.
-constexpr int RP = 280;
+// Row pass: LDS slot of point p of wave-line lw is lw*RP + p + (p >> 4).  gfx950 serves a ds_write_b64 16 lanes at a time on
+// (a/4) mod 32 and a ds_read_b64 32 lanes at a time on (a/4) mod 64 (MI355X_MICROARCH.md, LDS): an access pattern is free of
+// conflicts when the 8-byte slots of a 16-lane group differ mod 16 (stores) / of a 32-lane group mod 32 (loads).
+//   ALOHA_ROW_BMAP = 0 (shipped): B mapping lane = (lw = lane & 3, kh = lane >> 2), RP = 280 (== 24 mod 32): the first exchange
+//                       (A stores, B loads) is conflict-free, the trip back to the A mapping (B stores, A loads) is 2-way
+//                       conflicted on both sides: a third of the row kernels' LDS cycles are conflict cycles (VERDICT r3;
+//                       tests/test_lds_layout.py reproduces it from the two rules).
+//   ALOHA_ROW_BMAP = 1: lane = (kh = lane & 15, lw = lane >> 4), RP = 272 (== 16 mod 32): all four patterns conflict-free
+//                       (same test; PMC: SQ_LDS_BANK_CONFLICT 33.5 M -> 0 per headline launch, LDS cycles -33 %) -- and
+//                       SLOWER, measured in round 1 and again in round 4 at equal occupancy on one box
+//                       (profiles/r04_row_lds_layout_ab.txt: forward -0.4 %, inverse -1.3 %, HMult +1 %): the LDS is a quarter
+//                       busy in these kernels, its conflict cycles hide behind the butterflies, and the other lane mapping costs
+//                       registers (98 instead of 96 in the headline kernel: 4 waves per SIMD instead of 5 unless a twiddle
+//                       preload is given up).  Kept as a build knob with its test; not shipped.
+#ifndef ALOHA_ROW_BMAP
+#define ALOHA_ROW_BMAP 0
+#endif
+constexpr int RP = ALOHA_ROW_BMAP ? 272 : 280;
 // Per-lane twiddles issued ahead of the data they meet (measured in rounds 1-2, profiles/r01_w_*):
 constexpr int kInvColPreload = 15;   // inverse column pass: all 15 of the first step before the data loads (0 / 8 / 15: 2.38 / 2.38 / 2.44 M inverse NTT/s)
-constexpr int kRowPreload = 7;       // forward row pass: sub-stages 0..2 of the second step before the first step
+#ifndef ALOHA_ROW_PRELOAD
+#define ALOHA_ROW_PRELOAD 7
+#endif
+constexpr int kRowPreload = ALOHA_ROW_PRELOAD;   // forward row pass: sub-stages 0..2 of the second step before the first step
 constexpr int kInvRowPreload = 15;   // inverse row pass (0 / 12 / 15 = 2.44 / 2.45 / 2.48 M)
 
 // ---- scalar-sum prologue of a forward column tile ------------------------------------------------------------------
@@ -157,12 +175,12 @@ __device__ __forceinline__ void col_tile_inv(u64 *sdata, const LimbJob &jb, cons
 // ---- row pass: 256 contiguous points per line, 4 lines per WAVE ------------------------------------------------
 // A wave owns 4 lines and a private LDS region (4 x RP words), so the pass has no s_barrier at all (wave_lds_fence).
 // A mapping: lane (pl = lane & 15, lw = lane >> 4) holds points pl + 16k  -- 128-byte segments
-// B mapping: lane (lw = lane & 3, kh = lane >> 2) holds points 16*kh + j
+// B mapping: lane (kh, lw) holds points 16*kh + j; which lanes: ALOHA_ROW_BMAP above
 struct RowLanes {
   uint32_t plA, lwA, lwB, khB, ldsA, ldsB;
   __device__ __forceinline__ explicit RowLanes(int lane)
-      : plA(lane & 15), lwA(lane >> 4), lwB(lane & 3), khB(lane >> 2), ldsA((lane >> 4) * RP + (lane & 15)),
-        ldsB((lane & 3) * RP + 17 * (lane >> 2)) {}
+      : plA(lane & 15), lwA(lane >> 4), lwB(ALOHA_ROW_BMAP ? lane >> 4 : lane & 3), khB(ALOHA_ROW_BMAP ? lane & 15 : lane >> 2),
+        ldsA((lane >> 4) * RP + (lane & 15)), ldsB(lwB * RP + 17 * khB) {}
 };
 
 // entries 2^ss + g (ss = 0..3) of a twiddle block, as ordinary global loads in program order

@@ -21,6 +21,7 @@
 #include <array>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
 #include <unordered_map>
@@ -129,6 +130,9 @@ struct aloha_vp {
   uint32_t *d_prod_ctl = nullptr;
   uint8_t prod_tag[aloha::k::kProdMaxLimbs] = {0};   // the tag the words of each limb slot of d_prod_work carry (0: as allocated)
   bool prod_unchecked = false;                       // a product launch ran since the status word was last read
+  bool prod_disabled = false;                        // sticky: a product launch of this handle once gave up on a wait -- every later product takes the five-launch form
+  u64 *d_prod_fb = nullptr;                          // two limbs of scratch per product job for that form (allocated with d_prod_work)
+  bool capturing = false;                            // variant builds: a recorded run is being captured into a hipGraph
   // Launch lists of whole program runs, replayed when the same program segment is run again with the same CSRs
   // and the same architectural state on entry: the sequencer is a pure function of those (no data-dependent
   // control flow in the ISA), so a repeated phase of a key-switch costs its kernel launches and nothing else.
@@ -325,6 +329,46 @@ aloha_status get_slot(aloha_vp *vp, uint64_t q, unsigned logn, uint32_t *out) {
   return ALOHA_OK;
 }
 
+// ---- admission of one-launch polynomial products (ntt_product.hip) --------------------------------------------------------------
+// A product launch's later phases wait INSIDE the grid for its earlier ones.  Progress needs every XCD to dispatch each queue's
+// workgroups in order (observed, not promised by HIP); launches of several handles on different streams keep that property per
+// queue, but they share the chip's workgroup slots with one another's WAITING workgroups, and a wait that outlasts its bound
+// spoils an output.  So at most ONE handle per device has product launches in flight: a handle that finds another handle's launch
+// unfinished runs the same product as five ordinary launches (transforms, product, inverse transforms: the form of rounds 1-2,
+// word-identical results).  So does, for good, a handle whose status word was ever set (prod_disabled).
+struct ProdGate {
+  std::mutex mu;
+  const aloha_vp *owner = nullptr;
+  hipEvent_t done = nullptr;                         // recorded behind the owner's latest product launch
+  bool pending = false;
+};
+ProdGate &prod_gate(int device) {
+  static ProdGate gates[64];
+  return gates[(unsigned)device % 64];
+}
+// may `vp` launch a one-launch product now?  (called with the handle's device current)
+bool prod_admit(const aloha_vp *vp) {
+  ProdGate &g = prod_gate(vp->device);
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (g.owner && g.owner != vp && g.pending) {
+    if (hipEventQuery(g.done) != hipSuccess) { (void)hipGetLastError(); return false; }   // another handle's product is still in flight
+    g.pending = false;
+  }
+  g.owner = vp;
+  return true;
+}
+void prod_launched(const aloha_vp *vp, hipStream_t st) {
+  ProdGate &g = prod_gate(vp->device);
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.done && hipEventCreateWithFlags(&g.done, hipEventDisableTiming) != hipSuccess) { g.done = nullptr; (void)hipGetLastError(); return; }
+  if (g.owner == vp && hipEventRecord(g.done, st) == hipSuccess) g.pending = true;
+}
+void prod_release(const aloha_vp *vp) {              // the handle goes away (its stream has drained)
+  ProdGate &g = prod_gate(vp->device);
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (g.owner == vp) { g.owner = nullptr; g.pending = false; }
+}
+
 // After a synchronisation: did a fused transform give up on one of its bounded waits?  (It cannot in a correct
 // schedule -- see ntt_fused_fwd_kernel -- but a wait that can be bounded is, and the bound is reported.)
 aloha_status check_product(aloha_vp *vp) {
@@ -335,7 +379,9 @@ aloha_status check_product(aloha_vp *vp) {
   vp->prod_unchecked = false;
   if (!st) return ALOHA_OK;
   HIPCK(vp, hipMemsetAsync(vp->d_prod_ctl, 0, 64, vp->stream));
-  return fail(vp, ALOHA_ERR_DEVICE, "a fused polynomial product gave up on a bounded wait (%u waits): its output is incomplete", st);
+  vp->prod_disabled = true;                          // sticky: this handle's later products run as five ordinary launches
+  return fail(vp, ALOHA_ERR_DEVICE, "a one-launch polynomial product gave up on a bounded wait (%u waits): its output is incomplete; "
+                                    "the operands are intact (in-place products never take that form) and later products of this handle run as five launches", st);
 }
 
 aloha_status check_fused(aloha_vp *vp) {
@@ -544,6 +590,7 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   vp->iram_depth = cfg->iram_depth ? cfg->iram_depth : ALOHA_IRAM_DEPTH;
   if (const char *e = getenv("ALOHA_NTT_CHUNK")) vp->chunk_limbs = (uint32_t)strtoul(e, nullptr, 10);
   vp->run_cache_on = !getenv("ALOHA_NO_RUN_CACHE");          // (A/B switch: every run goes through the sequencer again)
+  vp->prod_disabled = getenv("ALOHA_PRODUCT_FALLBACK") != nullptr;   // (A/B and test switch: every polynomial product as five launches)
   if (const char *e = getenv("ALOHA_MAX_TWIDDLE_SETS")) vp->max_slots = std::min(kMaxPrimes, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));
 #ifdef ALOHA_EXPERIMENTS
   vp->graphs_on = getenv("ALOHA_RUN_GRAPH") != nullptr;
@@ -617,7 +664,9 @@ void aloha_vp_destroy(aloha_vp *vp) {
   if (vp->d_enc_in) (void)hipFree(vp->d_enc_in);
   if (vp->d_enc_work) (void)hipFree(vp->d_enc_work);
   if (vp->d_prod_work) (void)hipFree(vp->d_prod_work);
+  if (vp->d_prod_fb) (void)hipFree(vp->d_prod_fb);
   if (vp->d_prod_ctl) (void)hipFree(vp->d_prod_ctl);
+  prod_release(vp);
   if (vp->own_stream && vp->stream) (void)hipStreamDestroy(vp->stream);
   delete vp;
 }
@@ -828,7 +877,9 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           const uint64_t l0 = vp->stats.kernel_launches, f0 = vp->stats.fused_launches;
           bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
           if (ok) {
+            vp->capturing = true;
             for (const auto &op : pl.ops) ok = (op() == hipSuccess) && ok;
+            vp->capturing = false;
             hipGraph_t g = nullptr;
             ok = (hipStreamEndCapture(st, &g) == hipSuccess) && ok && g;
             if (ok) ok = hipGraphInstantiate(&pl.graph, g, nullptr, nullptr, 0) == hipSuccess;
@@ -1395,12 +1446,14 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     else if (pend_kind == PK_PROD && !prod_batch.empty()) {
       if (!vp->d_prod_ctl) {                                   // first product of this handle: scratch (tag 0 everywhere) and the status word
         const size_t ww = aloha::k::poly_product_work_words() * 8 + (1u << 20);   // (+ 1 MiB: clock stamps of trace builds)
-        if (hipMalloc(&vp->d_prod_work, ww) != hipSuccess || hipMalloc(&vp->d_prod_ctl, 64) != hipSuccess ||
+        const size_t fb = (size_t)2 * aloha::k::kProdMaxLimbs * 8 << 14;          // the five-launch form: two transformed operands per job
+        if (hipMalloc(&vp->d_prod_work, ww) != hipSuccess || hipMalloc(&vp->d_prod_ctl, 64) != hipSuccess || hipMalloc(&vp->d_prod_fb, fb) != hipSuccess ||
             hipMemsetAsync(vp->d_prod_work, 0, ww, st) != hipSuccess || hipMemsetAsync(vp->d_prod_ctl, 0, 64, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) {
           if (vp->d_prod_work) (void)hipFree(vp->d_prod_work);
           if (vp->d_prod_ctl) (void)hipFree(vp->d_prod_ctl);
-          vp->d_prod_work = nullptr; vp->d_prod_ctl = nullptr;
+          if (vp->d_prod_fb) (void)hipFree(vp->d_prod_fb);
+          vp->d_prod_work = nullptr; vp->d_prod_ctl = nullptr; vp->d_prod_fb = nullptr;
           s = fail(vp, ALOHA_ERR_DEVICE, "polynomial product: scratch allocation failed");
         }
         memset(vp->prod_tag, 0, sizeof vp->prod_tag);
@@ -1410,7 +1463,54 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
         const void *dj = nullptr;
         s = device_blob(vp, prod_batch.data() + j0, nj * sizeof(prod_batch[0]), &dj);
         if (s) break;
+        // The same products as five ordinary launches -- both operands' forward transforms as one batch, the products, the inverse
+        // transforms -- prepared beside the one-launch form: which of the two runs is decided when the launch is ISSUED (every
+        // replay of a recorded run decides again): the one-launch form unless another handle of this device has such a launch in
+        // flight or this handle's status word was ever set (prod_admit above).
+        const uint32_t nn = 1u << batch_logn, cnt2 = 2 * nj;
+        std::vector<LimbJob> F(2 * (size_t)cnt2), I(2 * (size_t)nj);
+        std::vector<aloha::k::EwJob> E(nj);
+        for (uint32_t i = 0; i < nj; i++) {
+          const aloha::k::ProdJob &pj = prod_batch[j0 + i];
+          u64 *wa = vp->d_prod_fb + ((size_t)(2 * i) << batch_logn), *wb = wa + nn;
+          F[2 * i] = LimbJob{pj.a, wa, pj.prime, 0, {0, 0, 0, 0}, 0};
+          F[2 * i + 1] = LimbJob{pj.b, wb, pj.prime, 0, {0, 0, 0, 0}, 0};
+          I[i] = LimbJob{wa, pj.d, pj.prime, 0, {0, 0, 0, 0}, 0};
+          aloha::k::EwJob e{};
+          e.d = wa; e.a = wa; e.b = wb; e.m = vp->slots[pj.prime].dev.m; e.op = (int)aloha::k::EW_MUL_VV;
+          E[i] = e;
+        }
+        for (uint32_t i = 0; i < cnt2; i++) { F[cnt2 + i] = F[i]; F[cnt2 + i].src = F[i].dst; }
+        for (uint32_t i = 0; i < nj; i++) { I[nj + i] = I[i]; I[nj + i].src = I[i].dst; }
+        std::vector<TileDesc> fu, fg, iu, ig;
+        aloha::k::build_row_tiles(F.data() + cnt2, 0, cnt2, batch_logn - 8, fu, fg);
+        aloha::k::build_row_tiles(I.data(), 0, nj, batch_logn - 8, iu, ig);
+        std::vector<TileDesc> ft(fu), it(iu);
+        ft.insert(ft.end(), fg.begin(), fg.end());
+        it.insert(it.end(), ig.begin(), ig.end());
+        const void *dF = nullptr, *dI = nullptr, *dE = nullptr, *dFt = nullptr, *dIt = nullptr;
+        s = device_blob(vp, F.data(), F.size() * sizeof(F[0]), &dF);
+        if (!s) s = device_blob(vp, I.data(), I.size() * sizeof(I[0]), &dI);
+        if (!s) s = device_blob(vp, E.data(), E.size() * sizeof(E[0]), &dE);
+        if (!s && !ft.empty()) s = device_blob(vp, ft.data(), ft.size() * sizeof(ft[0]), &dFt);
+        if (!s && !it.empty()) s = device_blob(vp, it.data(), it.size() * sizeof(it[0]), &dIt);
+        if (s) break;
+        const uint32_t nfu = (uint32_t)fu.size(), nfg = (uint32_t)fg.size(), niu = (uint32_t)iu.size(), nig = (uint32_t)ig.size();
+        const unsigned lg = batch_logn;
+        const unsigned single_max = (vp->flags & ALOHA_FLAG_NTT_TWO_PASS) ? 0u : (vp->flags & ALOHA_FLAG_NTT_SINGLE_14) ? 14u : 13u;
         const hipError_t e = issue(vp, [=]() -> hipError_t {
+          if (vp->capturing) return hipErrorStreamCaptureUnsupported;   // (the tag and the admission are decided per launch: not for a captured graph)
+          uint64_t launches = 0;
+          if (vp->prod_disabled || !prod_admit(vp)) {
+            const LimbJob *f = (const LimbJob *)dF, *iv = (const LimbJob *)dI;
+            const TileDesc *tf = (const TileDesc *)dFt, *ti = (const TileDesc *)dIt;
+            hipError_t e2 = aloha::k::ntt_tile_batch(st, f, f + cnt2, vp->d_primes, 0, cnt2, lg, false, tf, nfu, tf + nfu, nfg, &launches, single_max, false);
+            if (e2 == hipSuccess) { e2 = aloha::k::ew_batch(st, (const aloha::k::EwJob *)dE, nj, nn); launches++; }
+            if (e2 == hipSuccess) e2 = aloha::k::ntt_tile_batch(st, iv, iv + nj, vp->d_primes, 0, nj, lg, true, ti, niu, ti + niu, nig, &launches, single_max, false);
+            vp->stats.kernel_launches += launches;
+            vp->stats.product_fallbacks++;
+            return e2;
+          }
           // a tag none of the slots [0, nj) still carries (slots a smaller launch skipped keep older tags); if launches of
           // different sizes have left all four behind, the slots are wiped first
           uint32_t used = 0;
@@ -1423,11 +1523,11 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           uint32_t tag = 1;
           while (used & (1u << tag)) tag = (tag + 1) & 3;
           for (uint32_t i = 0; i < nj; i++) vp->prod_tag[i] = (uint8_t)tag;
-          uint64_t launches = 0;
           const hipError_t e2 = aloha::k::poly_product_batch(st, (const aloha::k::ProdJob *)dj, vp->d_primes, nj, vp->d_prod_work, vp->d_prod_ctl,
                                                              tag, &launches);
           vp->stats.kernel_launches += launches;
           vp->prod_unchecked = true;
+          if (e2 == hipSuccess) prod_launched(vp, st);
           return e2;
         });
         if (e != hipSuccess) s = fail(vp, ALOHA_ERR_DEVICE, "poly_product_batch: %s", hipGetErrorString(e));
@@ -1804,8 +1904,10 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
           ok = ok && zz;
           for (unsigned r = 0; ok && r < ALOHA_NVREG; r++)
             if (sym[r].kind >= S_NTT && !dead_from(vp, end + 1, r)) ok = false;
-          // the destination may BE an operand (its columns are read before they are written), not straddle one
-          if (ok && ((zz != pa && overlap(zz, pa, n)) || (zz != pb && overlap(zz, pb, n)))) ok = false;
+          // The destination may not touch an operand.  (The one-launch kernel could run in place -- its columns are read before they
+          // are written -- but a launch that gave up on a wait would then have destroyed its own input: with the operands intact the
+          // caller can run the program again, and the handle does so by itself through the five-launch form from then on.)
+          if (ok && (overlap(zz, pa, n) || overlap(zz, pb, n))) ok = false;
           if (ok) {
             if (!can_join(PK_PROD, logn, pa, pb, zz, n)) ALOHA_RUN_CK(flush());
             for (const auto &ld : loads) { lazy[ld.first].clear(); alias[ld.first] = ld.second; }

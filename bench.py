@@ -119,6 +119,18 @@ def self_launch(argv, gpus: int) -> int:
 
 
 
+def cpu_model() -> str:
+    """The host CPU's model name (SURVEY 8d / BASELINE.md 3 ask for core count AND model beside the CPU figures)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline(seconds: float = 8.0, check=None) -> dict:
     """The CPU path beside the GPU number: the oracle -- a scalar C port of the reference's
     arithmetic; the reference itself is RTL and no Verilog simulator exists (probed below) -- timed on
@@ -155,7 +167,7 @@ def cpu_baseline(seconds: float = 8.0, check=None) -> dict:
     multi, nm = rate(cores, a.shape[0], seconds / 2)
     oracle.set_threads(1)
     sims = [t for t in ("xsim", "vivado", "iverilog", "verilator", "vcs", "xrun") if shutil.which(t)]
-    return {"value": multi, "unit": "NTT/s", "cores": cores, "kind": "port",
+    return {"value": multi, "unit": "NTT/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "single_thread": single, "gpu_first_limb_equals_cpu": agrees,
             "sample": f"{nm} forward NTTs on {cores} threads + {n1} on one thread, N=2^16, one 60-bit prime, "
                       f"{seconds:.0f} s in all; Verilog simulators on this host: {sims or 'none'} "
@@ -176,7 +188,7 @@ CEILINGS = {
 }
 
 
-def configs_leg(device: int, budget_s: float = 55.0) -> dict:
+def configs_leg(device: int, budget_s: float = 85.0) -> dict:
     """BASELINE.json configs 2-5 on this GPU, bounded (the default bench run stays within minutes): per config the time, the
     ALGORITHMIC bytes by SURVEY.md 8d's formulas (aloha_amd/accounting.py; the itemised sum is printed), the fraction of the
     8 TB/s roofline, `verified` (every output word against the CPU oracle's ISA machine, in the untimed part) and the CPU
@@ -336,6 +348,57 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
     out["config4_hmult_relin_n65536_L24"] = keyswitch(24, "multiply")
     out["config5_rotate_keyswitch_n65536_L32"] = keyswitch(32, "rotate")
 
+    # -- configs 4 / 5 on the decomposition SURVEY 8d DEFINES them on: one digit per ciphertext prime and ONE special prime -- the
+    #    reference's own algorithm (keyswitch.mem:4-43 digits, :46-79 inner products, :80-121 mod-down), generated for L limbs by
+    #    aloha_amd/keyswitch.py in the reference's 4096-word ROM; dnum = L, K = 1: L (L + 1) digit transforms, 2 L (L + 1) key limbs
+    def keyswitch_reference(L, op):
+        from aloha_amd import keyswitch as refks
+        logn, n = 16, 1 << 16
+        mods = [avp.nth_prime(logn, i) for i in range(L)]
+        special = avp.nth_prime(logn, L)
+        lo = refks.Layout(n, mods, special)
+        sizes = dict(spm_rows=lo.spm_rows_needed, ksk_rows=lo.ksk_limbs * lo.rows)
+        k = pow(3, 5, 2 * n)
+        with avp.VP(max_log_n=16, device=device, **sizes) as vp:
+            ks = refks.ShardedKeySwitch(vp, n, mods, special)
+            vp.fill_synthetic(KSK, 0, logn, [lo.modulus(j) for j in range(L + 1) for _ in range(2 * L)], seed_base=0xA10A + 17000)
+            for base, seed in ((lo.ct_in, 3), (lo.ct_b, 4)):
+                vp.fill_synthetic(SPM, lo.row(base), logn, [mods[j] for _ in range(2) for j in range(L)], seed_base=0xA10A + 100000 * seed)
+            res = {}
+            # the CPU port needs ~4 s (L = 24) / ~8 s (L = 32) for this operation: verified here while the leg's budget lasts, and at full
+            # size in tests/test_keyswitch_sharded.py (GPU == the oracle's ISA machine) either way
+            verify = time.perf_counter() - t_start < budget_s - (14.0 if L > 24 else 9.0)
+            if verify:
+                o = oracle.OracleVP(**sizes)
+                ko = refks.ShardedKeySwitch(o, n, mods, special)
+                for jl in range(lo.Mr):                              # key limbs of one modulus at a time (the whole key is 0.6-1 GiB)
+                    o.write(KSK, jl * L * 2 * lo.rows, vp.read(KSK, jl * L * 2 * lo.rows, L * 2 * n))
+                for base in (lo.ct_in, lo.ct_b):
+                    o.write(SPM, lo.row(base), vp.read(SPM, lo.row(base), 2 * L * n))
+                t0 = time.perf_counter()
+                ko.multiply() if op == "multiply" else ko.rotate(k)
+                res["cpu_port_ms"] = (time.perf_counter() - t0) * 1e3
+            run = (lambda: ks.multiply()) if op == "multiply" else (lambda: ks.rotate(k))
+            run(); vp.sync()
+            if verify:
+                res["verified"] = bool(np.array_equal(ks.read_out(), ko.read_out()))
+                o.close()
+            else:
+                res["verified"] = None
+            l0 = vp.stats()["kernel_launches"]
+            run()
+            launches = float(vp.stats()["kernel_launches"] - l0)
+            t = timeit(run, vp.sync, 15)
+            by = acc.keyswitch_bytes(n, L, 1, L, op)
+            res.update({"ms": t * 1e3, "launches": launches, "L": L, "K": 1, "alpha": 1, "dnum": L, "iram_depth": 4096,
+                        "decomposition": "the reference's: one digit per prime, one special prime (keyswitch.mem:4-121 for L limbs)",
+                        "algorithmic_bytes": by, "GBps": by["survey_total"] / t / 1e9, "frac": by["survey_total"] / t / 1e9 / HBM_PEAK_GBS,
+                        "frac_lean": by["lean_total"] / t / 1e9 / HBM_PEAK_GBS})
+            return res
+
+    out["config4_hmult_relin_n65536_L24_reference_decomposition"] = keyswitch_reference(24, "multiply")
+    out["config5_rotate_keyswitch_n65536_L32_reference_decomposition"] = keyswitch_reference(32, "rotate")
+
     # -- config 5 as a BATCH of rotations: R rotations of one ciphertext share its decomposition (hoisting) and run in ONE pass of
     #    the phases (hybrid.rotate_hoisted_many: the batch slots of the layout serve as rotation slots, one key region each) ----------
     def rotation_batch(L, R):
@@ -396,8 +459,70 @@ def configs_leg(device: int, budget_s: float = 55.0) -> dict:
         t = timeit(run, vp.sync, 150)
         out["config5_automorphism_64limbs"] = {"us_per_limb": t / B * 1e6, "algorithmic_bytes": 16 * n * B, "GBps": 16 * n * B / t / 1e9,
                                                "frac": 16 * n * B / t / 1e9 / HBM_PEAK_GBS, "verified": ok, "cpu_port_ms_per_limb": cpu_ms}
+    out["reference_programs_n8192"] = reference_programs(device, timeit)
     out["seconds"] = time.perf_counter() - t_start
     return out
+
+
+def reference_programs(device: int, timeit) -> dict:
+    """The reference's OWN workload: its four instruction-ROM images (sim/vp/isram_file_generator/{encode_post,mul_plain,hom_add,
+    keyswitch}.mem at PC 0 / 64 / 160 / 256, loaded unchanged), N = 8192, two ciphertext primes + one special prime, on the golden
+    vectors of tv/case0_4_4.  The 8-op chain runs once and every dump is compared with the reference's RTL dumps (tests/golden,
+    fixtures made from tv/ by tests/golden/make_fixtures.py) -- golden data, not the oracle; then each program is timed by
+    itself, back to back, writing to a scratch ciphertext.  Beside each: the RTL's time DERIVED from its cycle model at the test
+    bench's 100 MHz (not a measurement) and the CPU port (the oracle's ISA machine, one thread)."""
+    import json as _json
+    import oracle
+    from aloha_amd import harness
+    from aloha_amd import vp as avp
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    man = _json.load(open(os.path.join(gdir, "manifest.json")))
+    ld = lambda e: np.fromfile(os.path.join(gdir, e["file"]), dtype="<u8")
+    images = {k: np.fromfile(os.path.join(gdir, man["isram"][k]["file"]), dtype="<u4").reshape(-1, 3) for k in ("encode_post", "mul_plain", "hom_add", "keyswitch")}
+    m = man["case0"]
+    H = harness
+    ops = [H.Op(H.OP_LOAD, 0x000, dram_addr=0), H.Op(H.OP_ROTATE, 0x100, src1=0x000, step=2),
+           H.Op(H.OP_ENCODE, 0x200, dram_addr=0x0), H.Op(H.OP_ENCODE, 0x280, dram_addr=0x40000),
+           H.Op(H.OP_MUL_PLAIN, 0x300, src1=0x000, src2=0x200), H.Op(H.OP_MUL_PLAIN, 0x400, src1=0x100, src2=0x280),
+           H.Op(H.OP_HOM_ADD, 0x500, src1=0x300, src2=0x400), H.Op(H.OP_STORE, 0x500, dram_addr=0x1000)]
+    n, kstep = 8192, pow(3, 2, 2 * 8192)
+    # (program, PC, src0, src1, step): the chain's own operands; every timed run writes the scratch ciphertext at row 0x600
+    progs = [("encode_post", 0, 0x200, 0, 0), ("mul_plain", 64, 0x000, 0x200, 0), ("hom_add", 160, 0x300, 0x400, 0), ("keyswitch_rotate", 256, 0x000, 0, kstep)]
+    rtl_cycles = {"encode_post": 2100, "mul_plain": 1200, "hom_add": 1300, "keyswitch_rotate": 20600}      # BASELINE.md section 2
+    res = {"note": "us_per_op: back-to-back runs of ONE program (aloha_vp_run at the reference's entry point), one GPU, operands resident; "
+                   "rtl_derived_us: DERIVED from the RTL's cycle model at the test bench's 100 MHz clock (BASELINE.md section 2), not measured"}
+    def chain(e):
+        tb = H.TestBench(e)
+        tb.load_programs({"encode_post": images["encode_post"], "mul_plain": images["mul_plain"], "hom_add": images["hom_add"], "keyswitch": images["keyswitch"]})
+        tb.load_ksk([ld(m["ksk_step2"])])
+        tb.dram_ct[0] = ld(m["inst_0_out"])
+        tb.dram_encoder[0x0] = ld(m["inst_2_0_out"]); tb.dram_encoder[0x40000] = ld(m["inst_3_0_out"])
+        dumps = {}
+        tb.dump = lambda k, sub, data: dumps.__setitem__(f"{k}{sub}", data)
+        tb.run(ops)
+        ok = True
+        for k in range(1, 8):
+            exp = ld(m[f"inst_{k}_out"])
+            ok = ok and bool(np.array_equal(dumps[str(k)][:exp.size], exp))
+        return ok
+    with avp.VP(spm_rows=0x800, ksk_rows=1024, max_log_n=13, device=device) as vp:
+        res["chain_case0_equals_rtl_dumps"] = chain(vp)
+        o = oracle.OracleVP(spm_rows=0x800, ksk_rows=1024)
+        chain(o)
+        for name, pc, s0, s1, step in progs:
+            run = lambda: vp.run(pc, src0=s0, src1=s1, rslt=0x600, ksk=0, step=step)
+            assert run() == 0
+            t0 = time.perf_counter(); assert o.run(pc, src0=s0, src1=s1, rslt=0x600, ksk=0, step=step) == 0; cpu_us = (time.perf_counter() - t0) * 1e6
+            same = bool(np.array_equal(vp.read(0, 0x600, 4 * n), o.read(0, 0x600, 4 * n)))     # (the scratch destination: GPU == CPU port, word for word)
+            l0 = vp.stats()["kernel_launches"]
+            assert run() == 0
+            launches = float(vp.stats()["kernel_launches"] - l0)
+            t = timeit(run, vp.sync, 250)
+            t1 = timeit(lambda: (run(), vp.sync()), vp.sync, 100)
+            res[name] = {"pc": pc, "us_per_op": t * 1e6, "single_call_with_sync_us": t1 * 1e6, "launches": launches, "rtl_derived_us": rtl_cycles[name] / 100.0,
+                         "cpu_port_us": cpu_us, "scratch_run_equals_cpu_port": same}
+        o.close()
+    return res
 
 
 def settle(step, sync, min_ms: float = 120.0, max_ms: float = 1500.0, block_ms: float = 20.0, tol: float = 0.01):

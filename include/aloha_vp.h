@@ -15,8 +15,9 @@
  *   DMA <-> SPM / KSK memory  run_load_cipher/run_store_cipher/
  *     copy_spm_to_dram/load_ksk  top_noaxilite_tb.sv:372-394,:450-520  aloha_vp_write / aloha_vp_read
  *   instruction semantics  src/vp/sequncer/expander.v:65-700           (executed inside run)
- *   (one extension: funct6 011101 `vautn`, the automorphism of vaut on an NTT-form limb; absent from
- *    every reference image)
+ *   (two extensions, absent from every reference image: funct6 011101 `vautn`, the automorphism of vaut on an
+ *    NTT-form limb, and funct6 100001 `vautz`, which stores q where vaut would have stored a sign-flipped zero as q
+ *    (vxu_lane.sv:598) -- with it iNTT(vautn(x)) equals the reference's vaut(iNTT(x)) word for word)
  *
  * Memory model: two row-addressed spaces, rows of 128 x u64 = 1024 bytes in
  * plain little-endian linear order (src/mem_buf/spm.sv:118-126, ksk_mem.sv:46-54).  A
@@ -40,7 +41,7 @@
 extern "C" {
 #endif
 
-#define ALOHA_VP_ABI_VERSION 3
+#define ALOHA_VP_ABI_VERSION 4
 
 typedef enum {
   ALOHA_OK = 0,
@@ -255,6 +256,8 @@ typedef struct {
   uint64_t graph_launches;  /* aloha_vp_run calls served by one hipGraphLaunch of a recorded run (ABI 2) */
   uint64_t twiddle_generations; /* times the bounded twiddle cache was emptied to make room (ABI 2)     */
   uint64_t ks_fused_launches;   /* of kernel_launches: key-switch kernels that absorbed neighbouring sums (ABI 3)  */
+  uint64_t product_fallbacks;   /* polynomial products (N = 2^14) run as five launches because another handle's one-launch product was
+                                   in flight on the device, or this handle's status word was once set (ABI 4)       */
 } aloha_vp_stats;
 aloha_status aloha_vp_get_stats(const aloha_vp *vp, aloha_vp_stats *out);
 /* copy a vector register to the host (debug; not architecturally visible in the reference) */

@@ -36,8 +36,37 @@ def test_header_symbols_all_exported(lib):
     assert sorted(set(avp.EXPORTS) | set(ks.EXPORTS)) == names          # the bindings (vp.py, ks.py) cover exactly the header
 
 
+def test_every_exported_symbol_is_in_the_integration_table(lib):
+    """INTEGRATION.md's table maps each entry point to the reference interface it replaces: every aloha_* symbol the LIBRARY
+    exports (read from its dynamic symbol table, not from the header) must have a row, and every function named in the table
+    must exist."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", avp.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("aloha_")})
+    assert exported == _declared_functions()                        # nothing exported beyond the header, nothing missing
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = "\n".join(ln for ln in text.splitlines() if ln.startswith("|"))
+    cells = " ".join(ln.split("|")[1] for ln in table.splitlines() if ln.count("|") >= 3)   # first column only
+    named = set()
+    for tok in re.findall(r"`([^`]+)`", cells):
+        # "aloha_vp_create / _destroy" names aloha_vp_create and aloha_vp_destroy
+        parts = [t.strip() for t in re.split(r"[/,]", tok)]
+        stem = None
+        for t in parts:
+            t = t.split("(")[0].strip()
+            if t.startswith("aloha_"):
+                named.add(t)
+                stem = t.rsplit("_", 1)[0]
+            elif t.startswith("_") and stem:
+                named.add(stem + t)
+    missing = [n for n in exported if n not in named]
+    assert not missing, f"exported but absent from INTEGRATION.md's entry-point table: {missing}"
+    ghosts = [n for n in named if n.startswith(("aloha_vp_", "aloha_ks_")) and n not in exported and "." not in n and n not in ("aloha_vp_stats", "aloha_vp_config")]
+    assert not ghosts, f"named in the table but not exported: {ghosts}"
+
+
 def test_abi_version_and_status_strings(lib):
-    assert lib.aloha_vp_abi_version() == 3
+    assert lib.aloha_vp_abi_version() == 4
     for s in range(12):
         assert lib.aloha_status_string(s)
     assert lib.aloha_status_string(0) == b"ok"
@@ -56,7 +85,7 @@ def test_create_rejects_bad_config(lib):
     h = ctypes.c_void_p()
     cfg = avp._Config(abi_version=99, device=0, spm_rows=1, ksk_rows=1, max_log_n=13, flags=0, stream=None)
     assert lib.aloha_vp_create(ctypes.byref(cfg), ctypes.byref(h)) == avp.ERR_ARG
-    cfg = avp._Config(abi_version=3, device=0, spm_rows=1, ksk_rows=1, max_log_n=17, flags=0, stream=None)
+    cfg = avp._Config(abi_version=4, device=0, spm_rows=1, ksk_rows=1, max_log_n=17, flags=0, stream=None)
     assert lib.aloha_vp_create(ctypes.byref(cfg), ctypes.byref(h)) == avp.ERR_ARG
     assert lib.aloha_vp_create(None, ctypes.byref(h)) == avp.ERR_ARG
 

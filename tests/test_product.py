@@ -109,10 +109,97 @@ def test_product_in_place_and_squaring():
     rng = np.random.default_rng(315)
     a = np.concatenate([residues(rng, N, q) for q in mods]); b = np.concatenate([residues(rng, N, q) for q in mods])
     words = programs.assemble(programs.poly_mul(N, mods))
-    # result over operand a, over operand b, and a * a
-    run_both(words, {0: a, L * ROWS: b}, 2 * L * ROWS, (0, 2 * L * N), launches=1, repeat=2, src0=0, src1=L * ROWS, rslt=0)
-    run_both(words, {0: a, L * ROWS: b}, 2 * L * ROWS, (0, 2 * L * N), launches=1, src0=0, src1=L * ROWS, rslt=L * ROWS)
+    # result over operand a, over operand b: NOT matched since round 4 (a one-launch product that gave up on a wait would have
+    # destroyed its own input) -- the program runs loop by loop, same words; a * a elsewhere: one launch
+    run_both(words, {0: a, L * ROWS: b}, 2 * L * ROWS, (0, 2 * L * N), launches=None, repeat=2, src0=0, src1=L * ROWS, rslt=0)
+    run_both(words, {0: a, L * ROWS: b}, 2 * L * ROWS, (0, 2 * L * N), launches=None, src0=0, src1=L * ROWS, rslt=L * ROWS)
     run_both(words, {0: a}, 2 * L * ROWS, (0, 2 * L * N), launches=1, src0=0, src1=0, rslt=L * ROWS)
+    with avp.VP(spm_rows=2 * L * ROWS, ksk_rows=1, max_log_n=LOGN) as vp:   # ... and the in-place form really is more than one launch
+        vp.write(SPM, 0, a); vp.write(SPM, L * ROWS, b); vp.load_isram(0, words)
+        k0 = vp.stats()["kernel_launches"]
+        assert vp.run(0, src0=0, src1=L * ROWS, rslt=0) == 0
+        vp.sync()
+        assert vp.stats()["kernel_launches"] - k0 > 1
+
+
+@pytest.mark.gpu
+def test_product_five_launch_form_is_word_identical(monkeypatch):
+    """The form a handle falls back to when another handle's one-launch product is in flight on the device (or its own status word
+    was once set): forward transforms of both operands as one batch, the products, the inverse transforms -- ALOHA_PRODUCT_FALLBACK
+    forces it.  Same words as the one-launch form and the oracle machine; the counter says which form ran."""
+    L = 8
+    mods = [oracle.nth_prime(LOGN, i % 3) for i in range(L)]
+    rng = np.random.default_rng(3141)
+    a = np.concatenate([residues(rng, N, q) for q in mods]); b = np.concatenate([residues(rng, N, q) for q in mods])
+    words = programs.assemble(programs.poly_mul(N, mods))
+    one = run_both(words, {0: a, L * ROWS: b}, 3 * L * ROWS, (2 * L * ROWS, L * N), launches=1, src0=0, src1=L * ROWS, rslt=2 * L * ROWS)
+    monkeypatch.setenv("ALOHA_PRODUCT_FALLBACK", "1")
+    five = run_both(words, {0: a, L * ROWS: b}, 3 * L * ROWS, (2 * L * ROWS, L * N), launches=5, repeat=3, src0=0, src1=L * ROWS, rslt=2 * L * ROWS)
+    assert np.array_equal(one, five)
+    with avp.VP(spm_rows=3 * L * ROWS, ksk_rows=1, max_log_n=LOGN) as vp:
+        vp.write(SPM, 0, a); vp.write(SPM, L * ROWS, b); vp.load_isram(0, words)
+        assert vp.run(0, src0=0, src1=L * ROWS, rslt=2 * L * ROWS) == 0
+        vp.sync()
+        assert vp.stats()["product_fallbacks"] == 1
+
+
+@pytest.mark.gpu
+def test_two_handles_running_64_limb_products_from_two_threads():
+    """two handles on two streams, each running 64-limb products (a grid of 2560 workgroups whose later phases
+    wait for the earlier ones) from its own thread, at the same time.  The admission rule lets ONE handle per device have such a
+    launch in flight; the other runs the five-launch form meanwhile.  Every result equals the oracle, no status word is set."""
+    import threading
+    Lb = 64
+    mods = [oracle.nth_prime(LOGN, i % 8) for i in range(Lb)]
+    words = programs.assemble(programs.poly_mul(N, mods))
+    rng = np.random.default_rng(3142)
+    data, want = [], []
+    for h in range(2):
+        a = np.concatenate([residues(rng, N, q) for q in mods]); b = np.concatenate([residues(rng, N, q) for q in mods])
+        data.append((a, b))
+        exp = []
+        for i in (0, 17, 63):                                     # three limbs per handle through the oracle (a full 64-limb product is ~0.3 s each)
+            fa, fb = oracle.ntt(a[i * N:(i + 1) * N], mods[i]), oracle.ntt(b[i * N:(i + 1) * N], mods[i])
+            prod = np.array([(int(x) * int(y)) % mods[i] for x, y in zip(fa, fb)], dtype=np.uint64)
+            exp.append((i, oracle.intt(prod, mods[i])))
+        want.append(exp)
+    vps = [avp.VP(spm_rows=3 * Lb * ROWS, ksk_rows=1, max_log_n=LOGN) for _ in range(2)]
+    errors, firsts = [], [None, None]
+    try:
+        for vp, (a, b) in zip(vps, data):
+            vp.write(SPM, 0, a); vp.write(SPM, Lb * ROWS, b); vp.load_isram(0, words)
+        barrier = threading.Barrier(2)
+
+        def work(h):
+            try:
+                vp = vps[h]
+                barrier.wait()
+                for rep in range(40):
+                    assert vp.run(0, src0=0, src1=Lb * ROWS, rslt=2 * Lb * ROWS) == 0
+                    if rep % 8 == 7:
+                        vp.sync()                                 # (raises if a status word was set)
+                        got = vp.read(SPM, 2 * Lb * ROWS, Lb * N)
+                        if firsts[h] is None:
+                            firsts[h] = got
+                        assert np.array_equal(got, firsts[h]), f"handle {h}: result changed between repetitions"
+                vp.sync()
+            except Exception as e:                                # noqa: BLE001
+                errors.append((h, e))
+
+        ts = [threading.Thread(target=work, args=(h,)) for h in range(2)]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        assert not errors, errors
+        for h in range(2):
+            for i, exp in want[h]:
+                assert np.array_equal(firsts[h][i * N:(i + 1) * N], exp), (h, i)
+        fallbacks = [vp.stats()["product_fallbacks"] for vp in vps]
+        launches = [vp.stats()["kernel_launches"] for vp in vps]
+        print("product_fallbacks per handle:", fallbacks, "kernel launches:", launches)
+        assert sum(fallbacks) > 0                                 # the two did meet: somebody took the five-launch form
+    finally:
+        for vp in vps:
+            vp.close()
 
 
 @pytest.mark.gpu
