@@ -203,35 +203,7 @@ __device__ __forceinline__ void row_tile(u64 *lds, const LimbJob *__restrict__ j
   if (!INV) {
     row_fwd_core<UNIA, FIRST ? FWD_IN : FWD_MID, LAST>(v, lds, L, blkA, blkB, pr);
   } else {
-    tw_t twb[15];
-#pragma unroll
-    for (int ss = 0; ss < 4; ss++)
-#pragma unroll
-      for (int g = 0; g < (1 << ss); g++)
-        if ((1 << ss) - 1 + g >= 15 - kInvRowPreload) {
-          const gtw_t p = (gtw_t)blkB + (16 << ss) + (L.khB << ss) + g;
-          twb[(1 << ss) - 1 + g].w = p->w;
-          twb[(1 << ss) - 1 + g].wp = p->wp;
-        }
-#pragma unroll
-    for (int kk = 0; kk < 16; kk++) lds[L.ldsA + 17 * kk] = v[kk];
-    wave_lds_fence();
-#pragma unroll
-    for (int jj = 0; jj < 16; jj++) v[jj] = lds[L.ldsB + jj];
-    inv_radix16<false, FIRST ? INV_IN : INV_MID, false>(v, TwStepMixHi<kInvRowPreload>{twb, blkB, (int)L.khB}, q, nq);
-    // lines with different blocks: the second step's 15 twiddles as ONE group of loads, in flight across the transpose
-    // (read at their use they are ~10 separately exposed latencies, see row_fwd_core)
-    tw_t twa[15];
-    if (!UNIA) load_tw15(twa, blkA);
-    // back to the A mapping: second inverse step / 128-byte-segment stores
-    wave_lds_fence();
-#pragma unroll
-    for (int jj = 0; jj < 16; jj++) lds[L.ldsB + jj] = v[jj];
-    wave_lds_fence();
-#pragma unroll
-    for (int kk = 0; kk < 16; kk++) v[kk] = lds[L.ldsA + 17 * kk];
-    if (UNIA) inv_radix16<true, INV_MID, false>(v, TwStepA{blkA}, q, nq);
-    else inv_radix16<false, INV_MID, false>(v, TwStepReg{twa}, q, nq);
+    row_inv_core<UNIA, FIRST ? INV_IN : INV_MID>(v, lds, L, blkA, blkB, pr);
     if (LAST) {
       const u64 ni = pr->tw.n_inv, nip = pr->tw.n_inv_shoup;
 #pragma unroll
@@ -244,13 +216,10 @@ __device__ __forceinline__ void row_tile(u64 *lds, const LimbJob *__restrict__ j
 
 // (the inverse instantiations settle at 100-134 VGPRs, 3-4 waves per SIMD; holding them to 96 costs 28 B of scratch and 2 %)
 // The forward bundle tiles need 94-98 VGPRs by layout: 96 (5 waves per SIMD) as shipped.  Two registers more cost a fifth of
-// the occupancy and 1 % of the headline; FORCING 96 (ALOHA_ROW_FWD_WAVES = 5) where the allocation wants 98 costs 20 B of scratch and
+// the occupancy and 1 % of the headline; FORCING 96 (amdgpu_waves_per_eu(5)) where the allocation wants 98 costs 20 B of scratch and
 // 3 % (profiles/r04_row_lds_layout_ab.txt).
-#ifndef ALOHA_ROW_FWD_WAVES
-#define ALOHA_ROW_FWD_WAVES 1
-#endif
 template <bool INV, bool UNIA, bool FIRST, bool LAST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!INV && UNIA) ? ALOHA_ROW_FWD_WAVES : 1))) void ntt_row_kernel(const LimbJob *__restrict__ jobs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void ntt_row_kernel(const LimbJob *__restrict__ jobs,
                                                                                               const PrimeDev *__restrict__ primes,
                                                                                               const TileDesc *__restrict__ tiles) {
   __shared__ u64 sdata[4 * RP];

@@ -242,6 +242,44 @@ __device__ __forceinline__ void row_fwd_core(u64 (&v)[16], u64 *lds, const RowLa
   for (int kk = 0; kk < 16; kk++) v[kk] = lds[L.ldsA + 17 * kk];
 }
 
+// The inverse transform of the wave's 4 lines (the FIRST pass of an inverse transform: strides 1..128 inside a 2 KiB row):
+// v (A mapping, < BIN*q) -> < INV_MID*q, back in the A mapping.  blkA / blkB: the line's INVERSE twiddle block as seen from the
+// lane's A / B line.  Shared by the plain row kernel (ntt_tile.hip) and the key-switch forms (ntt_ks.hip: the tensor product in
+// front of it, the inner products' accumulators in front of it).
+template <bool UNIA, int BIN>
+__device__ __forceinline__ void row_inv_core(u64 (&v)[16], u64 *lds, const RowLanes &L, ctw_t blkA, ctw_t blkB, const PrimeDev *pr) {
+  const u64 q = pr->m.q, nq = pr->m.nq;
+  tw_t twb[15];
+#pragma unroll
+  for (int ss = 0; ss < 4; ss++)
+#pragma unroll
+    for (int g = 0; g < (1 << ss); g++)
+      if ((1 << ss) - 1 + g >= 15 - kInvRowPreload) {
+        const gtw_t p = (gtw_t)blkB + (16 << ss) + (L.khB << ss) + g;
+        twb[(1 << ss) - 1 + g].w = p->w;
+        twb[(1 << ss) - 1 + g].wp = p->wp;
+      }
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++) lds[L.ldsA + 17 * kk] = v[kk];
+  wave_lds_fence();
+#pragma unroll
+  for (int jj = 0; jj < 16; jj++) v[jj] = lds[L.ldsB + jj];
+  inv_radix16<false, BIN, false>(v, TwStepMixHi<kInvRowPreload>{twb, blkB, (int)L.khB}, q, nq);
+  // lines with different blocks: the second step's 15 twiddles as ONE group of loads, in flight across the transpose
+  // (read at their use they are ~10 separately exposed latencies, see row_fwd_core)
+  tw_t twa[15];
+  if (!UNIA) load_tw15(twa, blkA);
+  // back to the A mapping: second inverse step / 128-byte-segment stores
+  wave_lds_fence();
+#pragma unroll
+  for (int jj = 0; jj < 16; jj++) lds[L.ldsB + jj] = v[jj];
+  wave_lds_fence();
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++) v[kk] = lds[L.ldsA + 17 * kk];
+  if (UNIA) inv_radix16<true, INV_MID, false>(v, TwStepA{blkA}, q, nq);
+  else inv_radix16<false, INV_MID, false>(v, TwStepReg{twa}, q, nq);
+}
+
 }  // namespace
 }  // namespace k
 }  // namespace aloha
