@@ -133,6 +133,10 @@ struct aloha_vp {
   bool prod_disabled = false;                        // sticky: a product launch of this handle once gave up on a wait -- every later product takes the five-launch form
   u64 *d_prod_fb = nullptr;                          // two limbs of scratch per product job for that form (allocated with d_prod_work)
   bool capturing = false;                            // variant builds: a recorded run is being captured into a hipGraph
+  // dataflow execution of small-ring programs (run_flow below): value buffers beside the vector registers
+  u64 *d_flow = nullptr;
+  size_t flow_bufs = 0;                              // limbs of 2^max_logn words in d_flow
+  bool flow_on = true;
   // Launch lists of whole program runs, replayed when the same program segment is run again with the same CSRs
   // and the same architectural state on entry: the sequencer is a pure function of those (no data-dependent
   // control flow in the ISA), so a repeated phase of a key-switch costs its kernel launches and nothing else.
@@ -591,6 +595,7 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   if (const char *e = getenv("ALOHA_NTT_CHUNK")) vp->chunk_limbs = (uint32_t)strtoul(e, nullptr, 10);
   vp->run_cache_on = !getenv("ALOHA_NO_RUN_CACHE");          // (A/B switch: every run goes through the sequencer again)
   vp->prod_disabled = getenv("ALOHA_PRODUCT_FALLBACK") != nullptr;   // (A/B and test switch: every polynomial product as five launches)
+  vp->flow_on = !getenv("ALOHA_NO_FLOW");                    // (A/B switch: small-ring programs through the in-order sequencer, as in rounds 1-3)
   if (const char *e = getenv("ALOHA_MAX_TWIDDLE_SETS")) vp->max_slots = std::min(kMaxPrimes, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));
 #ifdef ALOHA_EXPERIMENTS
   vp->graphs_on = getenv("ALOHA_RUN_GRAPH") != nullptr;
@@ -666,6 +671,7 @@ void aloha_vp_destroy(aloha_vp *vp) {
   if (vp->d_prod_work) (void)hipFree(vp->d_prod_work);
   if (vp->d_prod_fb) (void)hipFree(vp->d_prod_fb);
   if (vp->d_prod_ctl) (void)hipFree(vp->d_prod_ctl);
+  if (vp->d_flow) (void)hipFree(vp->d_flow);
   prod_release(vp);
   if (vp->own_stream && vp->stream) (void)hipStreamDestroy(vp->stream);
   delete vp;
@@ -836,6 +842,309 @@ aloha_status device_blob(aloha_vp *vp, const void *host, size_t bytes, const voi
   return ALOHA_OK;
 }
 
+// ---- dataflow execution of small-ring programs ----------------------------------------------------------------------------------
+// The in-order sequencer below batches what stands TOGETHER in a program: runs of `vle; op; vse` over memory operands.  The
+// reference's own programs are not written that way: keyswitch.mem:1-122 (N = 8192, two ciphertext primes and one special prime)
+// keeps its values in registers and interleaves the work of its limbs -- 18 transforms, 4 automorphisms, 38 element-wise
+// instructions, each a launch of its own on one 64 KiB limb: 60 launches of ~5 us, 307 us on the GPU against ~206 us derived
+// for the RTL (measured in round 4, bench.py `reference_programs_n8192`).  At such sizes a launch costs
+// its latency, not its work, so what a program costs is the DEPTH of its dependency graph, not its length.  For rings up to
+// N = 2^13 a program segment is therefore first turned into that graph:
+//   * registers are renamed (every write makes a new value with storage of its own: a pool buffer, or -- for a value that a
+//     `vse` stores and nothing conflicts with -- the stored rows themselves), `vle` aliases its rows, so only TRUE dependencies
+//     remain besides the memory hazards between loads and stores, which become edges too;
+//   * every operation gets the level 1 + max(level of what it depends on); the operations of one level are independent, and
+//     all of one kind leave as ONE batched launch (the same batched kernels the in-order sequencer uses);
+//   * operations whose results nobody reads are dropped (registers are not observable after `break`).
+// Every byte a `vse` writes is what sequential execution writes (the differential fuzz of tests/test_gpu_parity.py runs
+// random programs through this path, the in-order engine, the unfused engine and the oracle).  Anything irregular -- an
+// instruction that would fail, a vector-length change in mid-program, a ring above 2^13 -- is left to the in-order sequencer,
+// which reports errors with their program counter: planning has no side effects, `handled` stays false.
+struct FlowRange { const u64 *lo, *hi; };
+inline bool flow_hit(const FlowRange &a, const FlowRange &b) { return a.lo < b.hi && b.lo < a.hi; }
+
+aloha_status run_flow(aloha_vp *vp, uint32_t pc, const uint64_t csr[4], uint64_t step, bool *handled) {
+  *handled = false;
+  enum Kind { K_NTT, K_INTT, K_EW, K_AUT, K_COPY };
+  struct Val {
+    const u64 *fixed = nullptr;     // storage that exists already: rows a vle aliases, a vector register's slab, rows a vse targets
+    bool alias = false;             // fixed storage is SPM / KSK memory (a loaded value)
+    int producer = -1;              // operation that writes it (-1: exists on entry)
+    int buf = -1;                   // pool buffer, assigned after the levels are known
+    int def_level = 0, last_level = 0;
+  };
+  struct Op {
+    Kind kind;
+    int dst = -1, a = -1, b = -1;   // value ids
+    uint64_t q = 0, scalar = 0;
+    uint32_t prime = 0;
+    int ewop = 0;
+    uint32_t k = 0, kinv = 0, roll = 0;
+    std::vector<int> pred;
+    int level = 0;
+    bool live = false;
+  };
+  struct MemAcc { FlowRange r; int op; bool write; };
+  std::vector<Val> vals;
+  std::vector<Op> ops;
+  std::vector<MemAcc> acc;                                     // SPM / KSK accesses of the planned operations, in program order
+  int regs[ALOHA_NVREG];
+  for (unsigned r = 0; r < ALOHA_NVREG; r++) { Val v; v.fixed = vreg(vp, r); regs[r] = (int)vals.size(); vals.push_back(v); }
+  uint64_t vl = vp->vl_bits, q = vp->q, mu = vp->mu;
+  unsigned logn = 0;
+  uint32_t n = 0;
+  bool sized = false, touched = false;
+  uint64_t ninstr = 0;
+  auto resize = [&]() -> bool {
+    if (vl_logn(vl, vp->max_logn, &logn) != ALOHA_OK || logn > 13) return false;
+    n = 1u << logn; sized = true;
+    return true;
+  };
+  auto new_op = [&](Kind k) -> int { Op o; o.kind = k; o.q = q; ops.push_back(o); return (int)ops.size() - 1; };
+  auto depend = [&](int op, int on) { if (on >= 0 && on != op) ops[op].pred.push_back(on); };
+  auto in_memory = [&](int v) {                                // the value's storage is SPM / KSK rows (loaded from them, or placed there by a vse)
+    const u64 *f = vals[v].fixed;
+    return f && !(f >= vp->d_vreg && f < vp->d_vreg + ((size_t)ALOHA_NVREG << vp->max_logn));
+  };
+  // operation `op` reads value `v`: a true dependency on its producer; a read of memory if the value lives in rows
+  auto use = [&](int op, int v) {
+    depend(op, vals[v].producer);
+    if (in_memory(v)) {
+      const FlowRange r{vals[v].fixed, vals[v].fixed + n};
+      for (const MemAcc &m : acc) if (m.write && flow_hit(m.r, r)) depend(op, m.op);      // written earlier in the program
+      acc.push_back(MemAcc{r, op, false});
+    }
+  };
+  auto fresh = [&](int op) -> int { Val v; v.producer = op; vals.push_back(v); ops[op].dst = (int)vals.size() - 1; return ops[op].dst; };
+  uint32_t end_pc = pc;
+  for (uint32_t i = pc;; i++) {
+    if (i >= vp->iram_depth || ops.size() > 4096) return ALOHA_OK;                           // (no break / too long: not handled)
+    const Decoded d = decode_at(vp, i);
+    ninstr++;
+    const unsigned f6 = d.funct6;
+    if (f6 == 0x10) { end_pc = i; break; }
+    if (f6 == 0x00) continue;
+    if (f6 == 0x04) { if (touched && d.imm != vl) return ALOHA_OK; vl = d.imm; if (!resize()) return ALOHA_OK; continue; }
+    if (f6 == 0x08) { if (!modulus_ok(d.imm)) return ALOHA_OK; q = d.imm; continue; }
+    if (f6 == 0x0c) { mu = d.imm; continue; }
+    if (!sized && !resize()) return ALOHA_OK;
+    touched = true;
+    const bool needs_q = f6 != 0x03 && f6 != 0x07 && f6 != 0x19 && f6 != 0x1d;
+    if (needs_q && !(q > (1ull << 59) && q < (1ull << 60))) return ALOHA_OK;
+    switch (f6) {
+      case 0x03: {                                                 // vle: the register aliases the rows
+        const u64 *p = mem_rows(vp, d.imm, true, csr, n / kLanes);
+        if (!p) return ALOHA_OK;
+        Val v; v.fixed = p; v.alias = true;
+        regs[d.vd] = (int)vals.size(); vals.push_back(v);
+        break;
+      }
+      case 0x07: {                                                 // vse
+        u64 *p = mem_rows(vp, d.imm, false, csr, n / kLanes);
+        if (!p) return ALOHA_OK;
+        const FlowRange r{p, p + n};
+        const int v = regs[d.vs1];
+        if (in_memory(v)) {
+          if (vals[v].fixed == p) break;                          // rows stored onto themselves
+          if (flow_hit(FlowRange{vals[v].fixed, vals[v].fixed + n}, r)) return ALOHA_OK;   // a shifted self-overlap: left to the in-order sequencer
+        }
+        // registers whose value lives in rows this store overwrites keep the OLD contents: copied out first
+        for (unsigned rr = 0; rr < ALOHA_NVREG; rr++) {
+          const int a = regs[rr];
+          if (a == v || !in_memory(a) || !flow_hit(FlowRange{vals[a].fixed, vals[a].fixed + n}, r)) continue;
+          const int c = new_op(K_COPY);
+          ops[c].a = a; use(c, a);
+          fresh(c);
+          for (unsigned r2 = 0; r2 < ALOHA_NVREG; r2++) if (regs[r2] == a) regs[r2] = ops[c].dst;
+        }
+        // the producing operation may write the rows directly when nothing else planned so far touches them (an operation
+        // that reads exactly these rows as its own operand may: element-wise and transform kernels run in place)
+        const int pr = vals[v].producer;
+        bool direct = pr >= 0 && !vals[v].fixed && ops[pr].kind != K_COPY;
+        if (direct)
+          for (const MemAcc &m : acc) {
+            if (!flow_hit(m.r, r)) continue;
+            const bool own_operand = m.op == pr && !m.write && m.r.lo == r.lo && ops[pr].kind != K_AUT;
+            if (!own_operand) { direct = false; break; }
+          }
+        if (direct) {
+          vals[v].fixed = p;
+          acc.push_back(MemAcc{r, pr, true});
+          for (size_t o2 = (size_t)pr + 1; o2 < ops.size(); o2++)   // operations that read the value now read these rows
+            if (ops[o2].a == v || ops[o2].b == v) acc.push_back(MemAcc{r, (int)o2, false});
+        } else {
+          const int c = new_op(K_COPY);
+          ops[c].a = v; use(c, v);
+          for (const MemAcc &m : acc) if (flow_hit(m.r, r)) depend(c, m.op);            // after every earlier reader and writer of the rows
+          Val t; t.fixed = p; t.producer = c; vals.push_back(t); ops[c].dst = (int)vals.size() - 1;
+          acc.push_back(MemAcc{r, c, true});
+        }
+        break;
+      }
+      case 0x01: case 0x05: case 0x09: case 0x0d: case 0x11: {   // element-wise (the in-order sequencer's decode, expander.v:178-417)
+        aloha::k::EwOp op;
+        unsigned ra, rb = ALOHA_NVREG;
+        uint64_t s = 0;
+        if (f6 == 0x0d || f6 == 0x11) { ra = d.vs1; op = f6 == 0x0d ? aloha::k::EW_MOD : aloha::k::EW_CP; }
+        else if (d.funct3 == 0) {
+          if (((d.vs1 ^ d.vs2) & 1) == 0) return ALOHA_OK;
+          ra = d.vs1; rb = d.vs2;
+          op = f6 == 0x01 ? aloha::k::EW_MUL_VV : f6 == 0x05 ? aloha::k::EW_ADD_VV : aloha::k::EW_SUB_VV;
+        } else if (d.funct3 == 1) {
+          ra = d.vs1; s = d.imm;
+          op = f6 == 0x01 ? aloha::k::EW_MUL_VS : f6 == 0x05 ? aloha::k::EW_ADD_VS : aloha::k::EW_SUB_VS;
+        } else if (d.funct3 == 2 && f6 == 0x09) { ra = d.vs2; s = d.imm; op = aloha::k::EW_SUB_SV; }
+        else return ALOHA_OK;
+        s = s >= q ? s - q : s;
+        if (s >= q) return ALOHA_OK;
+        const int o = new_op(K_EW);
+        ops[o].ewop = (int)op; ops[o].scalar = s;
+        ops[o].a = regs[ra]; use(o, regs[ra]);
+        if (rb < ALOHA_NVREG) { ops[o].b = regs[rb]; use(o, regs[rb]); }
+        regs[d.vd] = fresh(o);
+        break;
+      }
+      case 0x15: case 0x19: case 0x1d: case 0x21: {                // vaut / vroli / vautn / vautz
+        if (f6 != 0x19 && !((step + d.imm) & 1)) return ALOHA_OK;
+        const uint64_t k = (step + d.imm) & (n - 1);
+        const int o = new_op(K_AUT);
+        ops[o].k = (uint32_t)k;
+        ops[o].roll = f6 == 0x19 ? 1 : f6 == 0x1d ? 2 : f6 == 0x21 ? 3 : 0;
+        if (ops[o].roll == 0 || ops[o].roll == 3) {
+          uint64_t kinv = 1;
+          for (int it = 0; it < 5; it++) kinv = kinv * (2 - k * kinv);
+          ops[o].kinv = (uint32_t)(kinv & (n - 1));
+        }
+        ops[o].a = regs[d.vs1]; use(o, regs[d.vs1]);
+        regs[d.vd] = fresh(o);
+        break;
+      }
+      case 0x02: case 0x06: {                                      // vntt / vintt
+        if ((q - 1) % (2ull << logn)) return ALOHA_OK;
+        const int o = new_op(f6 == 0x06 ? K_INTT : K_NTT);
+        ops[o].a = regs[d.vs1]; use(o, regs[d.vs1]);
+        regs[d.vd] = fresh(o);
+        break;
+      }
+      default: return ALOHA_OK;
+    }
+  }
+  (void)end_pc;
+  // ---- what is needed: operations that write memory, and what they depend on ----------------------------------------------
+  for (size_t i = ops.size(); i-- > 0;) {
+    Op &o = ops[i];
+    if (o.dst >= 0 && vals[o.dst].fixed && vals[o.dst].producer == (int)i && !vals[o.dst].alias &&
+        !(vals[o.dst].fixed >= vp->d_vreg && vals[o.dst].fixed < vp->d_vreg + ((size_t)ALOHA_NVREG << vp->max_logn)))
+      o.live = true;                                               // its destination is memory rows
+    if (!o.live) continue;
+    for (int p : o.pred) ops[p].live = true;
+  }
+  size_t nlive = 0;
+  int max_level = 0;
+  for (size_t i = 0; i < ops.size(); i++) {
+    Op &o = ops[i];
+    if (!o.live) continue;
+    nlive++;
+    int lv = 0;
+    for (int p : o.pred) if (ops[p].live) lv = std::max(lv, ops[p].level);
+    o.level = lv + 1;
+    max_level = std::max(max_level, o.level);
+    if (o.dst >= 0) { vals[o.dst].def_level = o.level; vals[o.dst].last_level = std::max(vals[o.dst].last_level, o.level); }
+    for (int v : {o.a, o.b}) if (v >= 0) vals[v].last_level = std::max(vals[v].last_level, o.level);
+  }
+  // ---- pool buffers for the values without storage of their own: an interval colouring over the levels ---------------------
+  std::vector<int> order;                                           // live values that need a buffer, by definition level
+  for (size_t v = 0; v < vals.size(); v++)
+    if (!vals[v].fixed && vals[v].producer >= 0 && ops[vals[v].producer].live) order.push_back((int)v);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return vals[x].def_level < vals[y].def_level; });
+  std::vector<int> free_at;                                         // per buffer: the last level at which it is read
+  for (int v : order) {
+    int b = -1;
+    for (size_t k = 0; k < free_at.size(); k++) if (free_at[k] < vals[v].def_level) { b = (int)k; break; }
+    if (b < 0) { b = (int)free_at.size(); free_at.push_back(0); }
+    free_at[b] = vals[v].last_level;
+    vals[v].buf = b;
+  }
+  if (free_at.size() > 1024) return ALOHA_OK;
+  // ---- from here on the run is executed -------------------------------------------------------------------------------------
+  *handled = true;
+  vp->vl_bits = vl; vp->q = q; vp->mu = mu;
+  vp->stats.instructions += ninstr;
+  if (!nlive) return ALOHA_OK;
+  if (free_at.size() > vp->flow_bufs) {
+    HIPCK(vp, hipStreamSynchronize(vp->stream));
+    if (vp->d_flow) { (void)hipFree(vp->d_flow); vp->d_flow = nullptr; vp->flow_bufs = 0; vp->epoch++; }   // recorded runs point into it
+    const size_t want = std::max<size_t>(free_at.size(), 16);
+    HIPCK(vp, hipMalloc(&vp->d_flow, (want * 8) << vp->max_logn));
+    vp->flow_bufs = want;
+  }
+  auto addr = [&](int v) -> u64 * {
+    const Val &x = vals[v];
+    return x.fixed ? const_cast<u64 *>(x.fixed) : vp->d_flow + ((size_t)x.buf << vp->max_logn);
+  };
+  hipStream_t st = vp->stream;
+  for (int lv = 1; lv <= max_level; lv++) {
+    std::vector<LimbJob> fwd, inv;
+    std::vector<aloha::k::EwJob> ew;
+    std::vector<aloha::k::AutJob> aut;
+    for (size_t i = 0; i < ops.size(); i++) {
+      const Op &o = ops[i];
+      if (!o.live || o.level != lv) continue;
+      switch (o.kind) {
+        case K_NTT: case K_INTT: {
+          uint32_t slot;
+          aloha_status s = get_slot(vp, o.q, logn, &slot);
+          if (s) return s;
+          (o.kind == K_NTT ? fwd : inv).push_back(LimbJob{addr(o.a), addr(o.dst), slot, 0, {0, 0, 0, 0}, 0});
+          break;
+        }
+        case K_EW: {
+          aloha::k::EwJob jb{};
+          jb.d = addr(o.dst); jb.a = addr(o.a); jb.b = o.b >= 0 ? addr(o.b) : jb.a;
+          jb.s = o.scalar; jb.s_shoup = aloha::nt::shoup(o.scalar, o.q); jb.m = modctx(o.q); jb.op = o.ewop;
+          ew.push_back(jb);
+          break;
+        }
+        case K_AUT: {
+          aloha::k::AutJob jb{};
+          jb.out = addr(o.dst); jb.in = addr(o.a); jb.q = o.q; jb.k = o.k; jb.k_inv = o.kinv; jb.roll = o.roll;
+          aut.push_back(jb);
+          break;
+        }
+        case K_COPY: {
+          u64 *cd = addr(o.dst); const u64 *cs = addr(o.a); const size_t cb = (size_t)n * 8;
+          if (cd != cs) HIPCK(vp, issue(vp, [=]() -> hipError_t { return hipMemcpyAsync(cd, cs, cb, hipMemcpyDeviceToDevice, st); }));
+          break;
+        }
+      }
+    }
+    // limbs that share a prime adjacent: one twiddle block per bundle of the transform kernels
+    auto by_prime = [](const LimbJob &x, const LimbJob &y) { return x.prime < y.prime; };
+    std::stable_sort(fwd.begin(), fwd.end(), by_prime);
+    std::stable_sort(inv.begin(), inv.end(), by_prime);
+    if (!fwd.empty()) { aloha_status s = run_transforms(vp, fwd, logn, false); if (s) return s; }
+    if (!inv.empty()) { aloha_status s = run_transforms(vp, inv, logn, true); if (s) return s; }
+    if (!ew.empty()) {
+      const void *dj = nullptr;
+      aloha_status s = device_blob(vp, ew.data(), ew.size() * sizeof(ew[0]), &dj);
+      if (s) return s;
+      const uint32_t nj = (uint32_t)ew.size(), nn = n;
+      HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::ew_batch(st, (const aloha::k::EwJob *)dj, nj, nn); }));
+    }
+    if (!aut.empty()) {
+      const void *dj = nullptr;
+      aloha_status s = device_blob(vp, aut.data(), aut.size() * sizeof(aut[0]), &dj);
+      if (s) return s;
+      const uint32_t nj = (uint32_t)aut.size();
+      const unsigned bl = logn;
+      // (the single-pass gather: at these sizes a launch is its latency, and the two coalesced passes are two launches)
+      HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::aut_batch(st, (const aloha::k::AutJob *)dj, nj, bl, false); }));
+    }
+  }
+  vp->stats.flow_runs++;
+  return ALOHA_OK;
+}
+
 }  // namespace
 
 extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_row, uint64_t src1_row,
@@ -949,6 +1258,14 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     }
   }
   const uint64_t epoch0 = vp->epoch;
+  if (fuse && vp->flow_on && !(vp->flags & ALOHA_FLAG_RADIX2_ONLY)) {   // small rings: by the program's dependency graph (run_flow above)
+    bool handled = false;
+    const aloha_status sf = run_flow(vp, pc, csr, step, &handled);
+    if (handled) {
+      if (!sf && vp->epoch == epoch0) finish_recording();
+      return sf;
+    }
+  }
   const u64 *alias[ALOHA_NVREG] = {nullptr};                // non-null: the register's value is memory at this address
   // Pending batch: deferred memory-to-memory jobs of ONE kind, launched together by flush().
   enum { PK_NONE, PK_NTT, PK_AUT, PK_EW, PK_DOT, PK_PROD } pend_kind = PK_NONE;

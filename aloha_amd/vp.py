@@ -57,7 +57,7 @@ class _Config(C.Structure):
 class _Stats(C.Structure):
     _fields_ = [("instructions", C.c_uint64), ("kernel_launches", C.c_uint64), ("twiddle_builds", C.c_uint64),
                 ("fused_launches", C.c_uint64), ("graph_launches", C.c_uint64),
-                ("twiddle_generations", C.c_uint64), ("ks_fused_launches", C.c_uint64), ("product_fallbacks", C.c_uint64)]
+                ("twiddle_generations", C.c_uint64), ("ks_fused_launches", C.c_uint64), ("product_fallbacks", C.c_uint64), ("flow_runs", C.c_uint64)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -250,7 +250,7 @@ class VP:
         return {"instructions": int(s.instructions), "kernel_launches": int(s.kernel_launches),
                 "twiddle_builds": int(s.twiddle_builds), "fused_launches": int(s.fused_launches),
                 "graph_launches": int(s.graph_launches), "twiddle_generations": int(s.twiddle_generations),
-                "ks_fused_launches": int(s.ks_fused_launches), "product_fallbacks": int(s.product_fallbacks)}
+                "ks_fused_launches": int(s.ks_fused_launches), "product_fallbacks": int(s.product_fallbacks), "flow_runs": int(s.flow_runs)}
 
     def peek_vreg(self, reg: int, n: int) -> np.ndarray:
         out = np.empty(n, dtype=np.uint64)

@@ -258,6 +258,7 @@ typedef struct {
   uint64_t ks_fused_launches;   /* of kernel_launches: key-switch kernels that absorbed neighbouring sums (ABI 3)  */
   uint64_t product_fallbacks;   /* polynomial products (N = 2^14) run as five launches because another handle's one-launch product was
                                    in flight on the device, or this handle's status word was once set (ABI 4)       */
+  uint64_t flow_runs;           /* aloha_vp_run calls sequenced by the program's dependency graph (rings up to N = 2^13; ABI 4)  */
 } aloha_vp_stats;
 aloha_status aloha_vp_get_stats(const aloha_vp *vp, aloha_vp_stats *out);
 /* copy a vector register to the host (debug; not architecturally visible in the reference) */
