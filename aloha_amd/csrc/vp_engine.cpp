@@ -1021,8 +1021,16 @@ aloha_status run_flow(aloha_vp *vp, uint32_t pc, const uint64_t csr[4], uint64_t
       }
       case 0x02: case 0x06: {                                      // vntt / vintt
         if ((q - 1) % (2ull << logn)) return ALOHA_OK;
+        int src = regs[d.vs1];
+        // `vcp t, x ; vntt vd, t` (keyswitch.mem:9-10,:13-14,:29-30,:33-34: a limb reinterpreted under another modulus): the forward
+        // transform takes any word < 2^60 < 2q and reduces as it goes, and vcp / vfqmod under the SAME modulus only subtract a
+        // multiple of q -- the transform of x is the transform of t, word for word, one level earlier
+        if (f6 == 0x02 && vals[src].producer >= 0) {
+          const Op &c = ops[vals[src].producer];
+          if (c.kind == K_EW && (c.ewop == (int)aloha::k::EW_CP || c.ewop == (int)aloha::k::EW_MOD) && c.q == q && !in_memory(c.a)) src = c.a;
+        }
         const int o = new_op(f6 == 0x06 ? K_INTT : K_NTT);
-        ops[o].a = regs[d.vs1]; use(o, regs[d.vs1]);
+        ops[o].a = src; use(o, src);
         regs[d.vd] = fresh(o);
         break;
       }
