@@ -865,7 +865,7 @@ inline bool flow_hit(const FlowRange &a, const FlowRange &b) { return a.lo < b.h
 
 aloha_status run_flow(aloha_vp *vp, uint32_t pc, const uint64_t csr[4], uint64_t step, bool *handled) {
   *handled = false;
-  enum Kind { K_NTT, K_INTT, K_EW, K_AUT, K_COPY };
+  enum Kind { K_NTT, K_INTT, K_EW, K_AUT, K_COPY, K_SUM };
   struct Val {
     const u64 *fixed = nullptr;     // storage that exists already: rows a vle aliases, a vector register's slab, rows a vse targets
     bool alias = false;             // fixed storage is SPM / KSK memory (a loaded value)
@@ -883,6 +883,14 @@ aloha_status run_flow(aloha_vp *vp, uint32_t pc, const uint64_t csr[4], uint64_t
     std::vector<int> pred;
     int level = 0;
     bool live = false;
+    // K_SUM: a tree of element-wise instructions under one modulus collapsed into  sum_t x_t * y_t + sum_t x_t * s_t + cst
+    std::vector<std::pair<int, int>> vv;           // products of two values
+    std::vector<std::pair<int, uint64_t>> lin;     // value times scalar
+    uint64_t cst = 0;
+    int into = -1;                                 // absorbed by that (later) operation
+    // K_INTT: `vintt ; vfqmul.vs c ; vfqadd.vs a` as ONE transform job (LimbJob::sc / addc: the scalar rides in the last stage)
+    bool scaled = false;
+    uint64_t mulc = 1, addc = 0;
   };
   struct MemAcc { FlowRange r; int op; bool write; };
   std::vector<Val> vals;
@@ -1038,15 +1046,141 @@ aloha_status run_flow(aloha_vp *vp, uint32_t pc, const uint64_t csr[4], uint64_t
     }
   }
   (void)end_pc;
+  // ---- trees of element-wise instructions as ONE pass each --------------------------------------------------------------------
+  // `vfqmul.vv t, a, b ; vfqadd.vv acc, acc, t` (keyswitch.mem:46-79) or `vfqsub.vv d, acc, t ; vfqmul.vs e, d, c ; vfqadd.vv r, r, e`
+  // (:102-117) are exact arithmetic mod q on canonical residues: a tree of such instructions under one modulus whose intermediate
+  // values have no other reader equals  sum x y + sum x s + cst  (mod q) over its leaves, which the sums' kernel evaluates in one
+  // pass (dot_batch: the in-order sequencer's lazy sums, there for memory operands only).  One level instead of the tree's depth.
+  // A leaf read moves to the time of the tree's root: refused when rows it reads are written in between.
+  {
+    std::vector<int> uses(vals.size(), 0);
+    for (const Op &o : ops) for (int v : {o.a, o.b}) if (v >= 0) uses[v]++;
+    auto mem_written_between = [&](int v, int from, int to) {      // is storage of value v (rows) written by an operation in (from, to)?
+      if (!in_memory(v)) return false;
+      const FlowRange r{vals[v].fixed, vals[v].fixed + n};
+      for (int w = from + 1; w < to; w++)
+        if (ops[w].dst >= 0 && in_memory(ops[w].dst) && flow_hit(FlowRange{vals[ops[w].dst].fixed, vals[ops[w].dst].fixed + n}, r)) return true;
+      return false;
+    };
+    // `vintt t, x ; [vfqmul.vs u, t, c ;] [vfqadd.vs | vfqsub.vs w, u, a]` (keyswitch.mem:80-83): the scalar rides in the transform's
+    // last stage, the constant on its canonical result -- the in-order sequencer's scaled transform job, here for register operands
+    if (logn >= 12)
+      for (int i = 0; i < (int)ops.size(); i++) {
+        Op &o = ops[i];
+        if (o.kind != K_EW || o.a < 0) continue;
+        const bool is_mul = o.ewop == (int)aloha::k::EW_MUL_VS, is_add = o.ewop == (int)aloha::k::EW_ADD_VS, is_sub = o.ewop == (int)aloha::k::EW_SUB_VS;
+        if (!is_mul && !is_add && !is_sub) continue;
+        const int v = o.a, p = vals[v].producer;
+        if (p < 0 || ops[p].kind != K_INTT || ops[p].q != o.q || uses[v] != 1 || vals[v].fixed || ops[p].addc) continue;
+        if (is_mul && ops[p].scaled) continue;
+        if (mem_written_between(ops[p].a, p, i)) continue;
+        const uint64_t c = ops[p].mulc, a0 = is_add ? o.scalar : is_sub ? (o.scalar ? o.q - o.scalar : 0) : 0;
+        o.kind = K_INTT; o.a = ops[p].a; o.b = -1; o.scaled = true;
+        o.mulc = is_mul ? o.scalar : c; o.addc = a0;
+        o.pred.insert(o.pred.end(), ops[p].pred.begin(), ops[p].pred.end());
+        ops[p].into = i;
+        uses[v] = 0;
+      }
+    struct Aff { std::vector<std::pair<int, int>> vv; std::vector<std::pair<int, uint64_t>> lin; uint64_t cst = 0; std::vector<int> absorbed; };
+    std::vector<Aff> aff(ops.size());
+    std::vector<char> has(ops.size(), 0);
+    // the sole reader of an instruction's result, when that is an element-wise instruction: a form that a scalar will multiply
+    // (vfqmul.vs, vfqsub.sv) must stay free of vector products, so it does not absorb them (they stay a sum of their own, a level
+    // earlier and usually off the critical path: (acc - t) * P^-1 + base is then ONE pass, keyswitch.mem:102-117)
+    std::vector<int> reader(ops.size(), -1);
+    for (int i = 0; i < (int)ops.size(); i++)
+      for (int v : {ops[i].a, ops[i].b})
+        if (v >= 0 && vals[v].producer >= 0 && uses[v] == 1) reader[vals[v].producer] = i;
+    auto scalar_reader = [&](int i) {
+      const int r = reader[i];
+      return r >= 0 && ops[r].kind == K_EW && ops[r].q == ops[i].q && (ops[r].ewop == (int)aloha::k::EW_MUL_VS || ops[r].ewop == (int)aloha::k::EW_SUB_SV);
+    };
+    for (int i = 0; i < (int)ops.size(); i++) {
+      Op &o = ops[i];
+      if (o.kind != K_EW) continue;
+      const uint64_t qq = o.q;
+      auto neg = [&](uint64_t x) { return x ? qq - x : 0; };
+      // an operand as an affine form: the tree below it if it may be absorbed, else the value itself as a leaf
+      const bool no_vv = scalar_reader(i);
+      auto operand = [&](int v, bool allow_vv) -> Aff {
+        const int p = vals[v].producer;
+        if (no_vv) allow_vv = false;
+        if (p >= 0 && ops[p].into < 0 && has[p] && ops[p].q == qq && uses[v] == 1 && !vals[v].fixed && (allow_vv || aff[p].vv.empty())) {
+          bool ok = true;
+          std::vector<int> all(aff[p].absorbed); all.push_back(p);
+          for (int a : all) for (int x : {ops[a].a, ops[a].b}) if (x >= 0 && mem_written_between(x, a, i)) ok = false;
+          if (ok) { Aff f = aff[p]; f.absorbed.push_back(p); return f; }
+        }
+        Aff f; f.lin.emplace_back(v, 1); return f;
+      };
+      Aff r;
+      bool ok = true;
+      switch ((aloha::k::EwOp)o.ewop) {
+        case aloha::k::EW_MUL_VV: r.vv.emplace_back(o.a, o.b); break;
+        case aloha::k::EW_CP: case aloha::k::EW_MOD: r = operand(o.a, true); break;
+        case aloha::k::EW_ADD_VV: case aloha::k::EW_SUB_VV: {
+          r = operand(o.a, true);
+          Aff y = operand(o.b, o.ewop == (int)aloha::k::EW_ADD_VV);
+          if (o.ewop == (int)aloha::k::EW_SUB_VV) { for (auto &t : y.lin) t.second = neg(t.second); y.cst = neg(y.cst); }
+          r.vv.insert(r.vv.end(), y.vv.begin(), y.vv.end());
+          r.lin.insert(r.lin.end(), y.lin.begin(), y.lin.end());
+          r.cst = (r.cst + y.cst) % qq;
+          r.absorbed.insert(r.absorbed.end(), y.absorbed.begin(), y.absorbed.end());
+          break;
+        }
+        case aloha::k::EW_MUL_VS: {
+          r = operand(o.a, false);
+          for (auto &t : r.lin) t.second = aloha::nt::mulmod(t.second, o.scalar, qq);
+          r.cst = aloha::nt::mulmod(r.cst, o.scalar, qq);
+          break;
+        }
+        case aloha::k::EW_ADD_VS: r = operand(o.a, true); r.cst = (r.cst + o.scalar) % qq; break;
+        case aloha::k::EW_SUB_VS: r = operand(o.a, true); r.cst = (r.cst + neg(o.scalar)) % qq; break;
+        case aloha::k::EW_SUB_SV: {
+          r = operand(o.a, false);
+          for (auto &t : r.lin) t.second = neg(t.second);
+          r.cst = (neg(r.cst) + o.scalar) % qq;
+          break;
+        }
+        default: ok = false;
+      }
+      if (!ok || r.vv.size() + r.lin.size() + 1 > (size_t)aloha::k::kDotTerms) continue;     // (stays a plain instruction, a leaf for its readers)
+      aff[i] = r; has[i] = 1;
+    }
+    // roots: forms that absorbed something and are not absorbed themselves
+    std::vector<char> gone(ops.size(), 0);
+    for (int i = (int)ops.size() - 1; i >= 0; i--) {
+      if (!has[i] || gone[i] || aff[i].absorbed.empty()) continue;
+      Op &o = ops[i];
+      o.kind = K_SUM; o.vv = aff[i].vv; o.lin = aff[i].lin; o.cst = aff[i].cst;
+      for (int a : aff[i].absorbed) {
+        gone[a] = 1; ops[a].into = i;
+        o.pred.insert(o.pred.end(), ops[a].pred.begin(), ops[a].pred.end());
+      }
+    }
+    for (Op &o : ops)                                               // edges to an absorbed instruction now lead to the sum that holds it
+      for (int &p2 : o.pred) { while (ops[p2].into >= 0) p2 = ops[p2].into; }
+    for (int i = 0; i < (int)ops.size(); i++) {
+      Op &o = ops[i];
+      o.pred.erase(std::remove(o.pred.begin(), o.pred.end(), i), o.pred.end());
+    }
+  }
   // ---- what is needed: operations that write memory, and what they depend on ----------------------------------------------
   for (size_t i = ops.size(); i-- > 0;) {
     Op &o = ops[i];
     if (o.dst >= 0 && vals[o.dst].fixed && vals[o.dst].producer == (int)i && !vals[o.dst].alias &&
         !(vals[o.dst].fixed >= vp->d_vreg && vals[o.dst].fixed < vp->d_vreg + ((size_t)ALOHA_NVREG << vp->max_logn)))
       o.live = true;                                               // its destination is memory rows
+    if (o.into >= 0) o.live = false;                               // (its arithmetic happens inside the sum that absorbed it)
     if (!o.live) continue;
     for (int p : o.pred) ops[p].live = true;
   }
+  auto operands_of = [&](const Op &o, std::vector<int> &out) {
+    out.clear();
+    if (o.kind == K_SUM) { for (const auto &t : o.vv) { out.push_back(t.first); out.push_back(t.second); } for (const auto &t : o.lin) out.push_back(t.first); }
+    else { if (o.a >= 0) out.push_back(o.a); if (o.b >= 0) out.push_back(o.b); }
+  };
+  std::vector<int> opnds;
   size_t nlive = 0;
   int max_level = 0;
   for (size_t i = 0; i < ops.size(); i++) {
@@ -1058,7 +1192,8 @@ aloha_status run_flow(aloha_vp *vp, uint32_t pc, const uint64_t csr[4], uint64_t
     o.level = lv + 1;
     max_level = std::max(max_level, o.level);
     if (o.dst >= 0) { vals[o.dst].def_level = o.level; vals[o.dst].last_level = std::max(vals[o.dst].last_level, o.level); }
-    for (int v : {o.a, o.b}) if (v >= 0) vals[v].last_level = std::max(vals[v].last_level, o.level);
+    operands_of(o, opnds);
+    for (int v : opnds) vals[v].last_level = std::max(vals[v].last_level, o.level);
   }
   // ---- pool buffers for the values without storage of their own: an interval colouring over the levels ---------------------
   std::vector<int> order;                                           // live values that need a buffer, by definition level
@@ -1095,15 +1230,34 @@ aloha_status run_flow(aloha_vp *vp, uint32_t pc, const uint64_t csr[4], uint64_t
     std::vector<LimbJob> fwd, inv;
     std::vector<aloha::k::EwJob> ew;
     std::vector<aloha::k::AutJob> aut;
+    std::vector<aloha::k::DotArgs> sums;
     for (size_t i = 0; i < ops.size(); i++) {
       const Op &o = ops[i];
       if (!o.live || o.level != lv) continue;
       switch (o.kind) {
+        case K_SUM: {
+          aloha::k::DotArgs g{};
+          int t = 0;
+          for (const auto &x : o.vv) { g.a[t] = addr(x.first); g.b[t] = addr(x.second); t++; }
+          for (const auto &x : o.lin) { g.a[t] = addr(x.first); g.b[t] = nullptr; g.s[t] = x.second; g.sp[t] = aloha::nt::shoup(x.second, o.q); t++; }
+          if (o.cst) { g.a[t] = nullptr; g.b[t] = nullptr; g.s[t] = o.cst; t++; }
+          g.nterms = t; g.init = nullptr; g.d = addr(o.dst); g.m = modctx(o.q);
+          sums.push_back(g);
+          break;
+        }
         case K_NTT: case K_INTT: {
           uint32_t slot;
           aloha_status s = get_slot(vp, o.q, logn, &slot);
           if (s) return s;
-          (o.kind == K_NTT ? fwd : inv).push_back(LimbJob{addr(o.a), addr(o.dst), slot, 0, {0, 0, 0, 0}, 0});
+          LimbJob jb{addr(o.a), addr(o.dst), slot, 0, {0, 0, 0, 0}, 0};
+          if (o.kind == K_INTT && o.scaled) {
+            const auto &tt = vp->slots[slot].dev.tw;
+            jb.scaled = 1;
+            jb.sc[0] = aloha::nt::mulmod(tt.w1n_inv, o.mulc, o.q); jb.sc[1] = aloha::nt::shoup(jb.sc[0], o.q);
+            jb.sc[2] = aloha::nt::mulmod(tt.n_inv, o.mulc, o.q);   jb.sc[3] = aloha::nt::shoup(jb.sc[2], o.q);
+            jb.addc = o.addc;
+          }
+          (o.kind == K_NTT ? fwd : inv).push_back(jb);
           break;
         }
         case K_EW: {
@@ -1138,6 +1292,13 @@ aloha_status run_flow(aloha_vp *vp, uint32_t pc, const uint64_t csr[4], uint64_t
       if (s) return s;
       const uint32_t nj = (uint32_t)ew.size(), nn = n;
       HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::ew_batch(st, (const aloha::k::EwJob *)dj, nj, nn); }));
+    }
+    if (!sums.empty()) {
+      const void *dj = nullptr;
+      aloha_status s = device_blob(vp, sums.data(), sums.size() * sizeof(sums[0]), &dj);
+      if (s) return s;
+      const uint32_t nj = (uint32_t)sums.size(), nn = n;
+      HIPCK(vp, issue(vp, [=]() -> hipError_t { vp->stats.kernel_launches++; return aloha::k::dot_batch(st, (const aloha::k::DotArgs *)dj, nj, nn); }));
     }
     if (!aut.empty()) {
       const void *dj = nullptr;
