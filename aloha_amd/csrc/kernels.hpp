@@ -204,6 +204,8 @@ hipError_t ntt_fwd16_cols(hipStream_t st, const LimbJob *d_jobs, const PrimeDev 
 // row pass over the tile lists (in place on the jobs' dst); jobs with `epi` end in their epilogue (d_epis)
 hipError_t ntt_fwd16_rows(hipStream_t st, const LimbJob *d_inplace, const PrimeDev *d_primes, const TileDesc *d_uni_tiles, uint32_t n_uni,
                           const TileDesc *d_glb_tiles, uint32_t n_glb, const RowEpi *d_epis, uint64_t *launches);
+// inverse column pass at N = 2^16, in place on the jobs' dst (`scaled`: some job carries its own last-stage scalar)
+hipError_t ntt_inv16_cols(hipStream_t st, const LimbJob *d_inplace, const PrimeDev *d_primes, uint32_t count, bool scaled, uint64_t *launches);
 // row pass of every group's transformed digits + inner product with the key, one launch
 hipError_t ntt_fwd16_rowdot(hipStream_t st, const RowDotGroup *d_groups, uint32_t ngroups, const PrimeDev *d_primes, uint64_t *launches);
 

@@ -336,6 +336,12 @@ static void launch_rows(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d
   if (launches) ++*launches;
 }
 
+hipError_t ntt_inv16_cols(hipStream_t st, const LimbJob *d_inplace, const PrimeDev *d_primes, uint32_t count, bool scaled, uint64_t *launches) {
+  if (scaled) launch_cols<true, false, true, true>(st, d_inplace, d_primes, count, launches);
+  else launch_cols<true, false, true>(st, d_inplace, d_primes, count, launches);
+  return hipGetLastError();
+}
+
 hipError_t ntt_radix2_batch(hipStream_t st, const LimbJob *d_jobs, const PrimeDev *d_primes, uint32_t count,
                             unsigned logn, unsigned stage_begin, unsigned stage_end, bool inverse,
                             bool first_reads_src, bool last_scales, uint64_t *launches) {

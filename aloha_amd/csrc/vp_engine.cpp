@@ -1815,6 +1815,9 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
   // (d0 = a0 b0, d2 = a1 b1) and a two-term sum (d1 = a0 b1 + a1 b0) over the same four limbs.  The batch of products is
   // held when sums follow; at the flush every (d0, d2, d1) triple over one quadruple of operands leaves as ONE job of
   // tensor_batch (each input read once: 7 limb passes instead of 11), the rest as before, in stage order.
+  // (Round 4, measured and dropped: the tensor product formed INSIDE the inverse row pass that transforms its d2 -- HMult's first phase as
+  // one launch less and d2 never read back: 32.6 us against 18.0 + 15.8 us for the two kernels.  The inverse transform of 24 limbs is a
+  // latency-bound launch of 1.5 waves per SIMD; work moved into it is not hidden, it is serialised.  profiles/r04_tensor_in_inverse_row_pass.txt)
   std::vector<aloha::k::EwJob> held_ew;
   auto launch_tensor = [&]() -> aloha_status {
     std::vector<aloha::k::EwJob> E;
