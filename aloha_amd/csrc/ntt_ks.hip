@@ -37,6 +37,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 // Row pass (second pass of a forward transform) whose lines may end in an epilogue.  A line with an epilogue is not
 // canonicalised first: its Shoup product takes any 64-bit value.
+// (amdgpu_waves_per_eu(4) brings the <false> form from 136 to 128 VGPRs and four waves per SIMD without scratch: measured within
+// the noise, HMult 0.2703 against 0.2706 ms -- profiles/r04_ks_kernel_experiments.txt)
 template <bool UNIA>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void ntt_row_epi_kernel(const LimbJob *__restrict__ jobs,
                                                                                                  const PrimeDev *__restrict__ primes,
@@ -191,6 +193,10 @@ __device__ __forceinline__ void products_chunk(const u64 (&v)[16], int m, cgptr_
 // (Round 4, measured and dropped: touching the lines of a tile's key rows -- one dword per 128-byte line and lane, between the two
 // radix-16 steps of the tile's transform -- so that the products' loads find them in L2 / the Infinity Cache: HMult 0.283 against
 // 0.272 ms, rotate 0.401 against 0.393: the extra requests cost more than the latency they hide, profiles/r04_row_lds_layout_ab.txt.)
+// (Round 4, built, bit-exact, measured and removed -- profiles/r04_ks_kernel_experiments.txt: the FIRST pass of the special-prime
+// accumulators' inverse transforms as a tail of this kernel (the wave holds complete rows of both accumulators; phases 2 and 3 as one
+// program so that the sequencer sees the chain): one launch and 9 us of latency-bound row pass less, and HMult 0.2794 against 0.2766 ms,
+// rotate 0.4008 against 0.3953 on one box -- the tail's waves are the last to finish and its code costs the whole kernel ~5 us.)
 // S waves per workgroup share the digits of one (group, R rows): each takes a contiguous share of the blocks, wave 0 adds the
 // accumulators of the others (through LDS) and stores.  A wave's chain of tiles is serial -- load, transform, load the
 // key, multiply -- and a key-switch has few groups, so at S = 1 the kernel's time was one wave's latency (the same ~100 us for
@@ -386,7 +392,7 @@ hipError_t ntt_fwd16_rowdot(hipStream_t st, const RowDotGroup *d_groups, uint32_
   static const int forced = getenv("ALOHA_ROWDOT_ROWS") ? atoi(getenv("ALOHA_ROWDOT_ROWS")) : 0;
   static const int forced_split = getenv("ALOHA_ROWDOT_SPLIT") ? atoi(getenv("ALOHA_ROWDOT_SPLIT")) : 0;
   const bool two = forced ? forced == 2 : ngroups < 96;
-  const bool split = forced_split ? forced_split == 2 : ngroups < 48;
+  const bool split = forced_split ? forced_split == 2 : ngroups < 48;          // (S = 4, round 4: 0.292 against 0.271 ms; S = 1 equals S = 2 by now: profiles/r04_ks_kernel_experiments.txt)
   if (two && split) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 2>), dim3(ngroups * 128), dim3(128), 0, st, d_groups, d_primes);
   else if (two) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 1>), dim3(ngroups * 128), dim3(64), 0, st, d_groups, d_primes);
   else hipLaunchKernelGGL((ntt_rowdot_kernel<4, 1>), dim3(ngroups * 64), dim3(64), 0, st, d_groups, d_primes);
