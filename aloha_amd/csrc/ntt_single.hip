@@ -115,18 +115,27 @@ __global__ __launch_bounds__((1 << LOGN) / 16) __attribute__((amdgpu_waves_per_e
   const uint32_t a1 = t >> (LOGN - 8), a2 = t >> E;           // upper index bits of the thread in L1 / L2
   u64 v[16];
 
-  auto exchange = [&](auto from, auto to, bool wave_private) {   // registers: layout `from` -> layout `to`
+  auto exchange = [&](auto from, auto to, bool wave_private) {   // registers: layout `from` -> layout `to` (LDS word of register r)
 #pragma unroll
-    for (int r = 0; r < 16; r++) lds[swz<LOGN>(from(t, r))] = v[r];
+    for (int r = 0; r < 16; r++) lds[from(r)] = v[r];
     if (wave_private) wave_lds_fence(); else __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = lds[swz<LOGN>(to(t, r))];
+    for (int r = 0; r < 16; r++) v[r] = lds[to(r)];
     if (wave_private) wave_lds_fence();                        // (the next write phase reuses the same words)
   };
-  auto L0 = [](uint32_t tt, uint32_t r) { return lay<LOGN, 0>(tt, r); };
-  auto L1 = [](uint32_t tt, uint32_t r) { return lay<LOGN, 1>(tt, r); };
-  auto L2 = [](uint32_t tt, uint32_t r) { return lay<LOGN, 2>(tt, r); };
-  auto L3 = [](uint32_t tt, uint32_t r) { return lay3<LOGN>(tt, r); };
+  // LDS word of register r in each layout.  At N = 2^13 -- the reference's ring, every tv/ vector -- in CLOSED FORM: the swizzle
+  // only touches index bits 0..4, so the word is (a per-lane base XOR a 5-bit constant of r) + (r's own bits, an instruction
+  // immediate): 0 / 1 / 1 / 0 vector instructions per access for L0 / L1 / L2 / L3 where the compiler derived ~3 from
+  // swz(lay(t, r)) -- 14 % of the kernel's instructions, in a kernel that is VALU-bound (round 4; the identities are checked
+  // exhaustively against swz / lay in tests/test_lds_layout.py).
+  const uint32_t cA0 = t ^ (t >> 4) ^ ((t >> 5) & 15);
+  const uint32_t cB1 = (((t >> 5) << 9) | (t & 31)) ^ ((t >> 4) & 1) ^ (((t >> 5) & 1) << 4);
+  const uint32_t cC2 = (((t >> 1) << 5) | (t & 1)) ^ (((t >> 1) & 15) << 1) ^ ((t >> 1) & 31);
+  const uint32_t cA3 = (t << 1) ^ ((t >> 3) & 31) ^ ((t >> 4) & 31);
+  auto L0 = [&](uint32_t r) -> uint32_t { if constexpr (LOGN == 13) return (cA0 ^ ((r & 1) << 4)) + (r << 9); else return swz<LOGN>(lay<LOGN, 0>(t, r)); };
+  auto L1 = [&](uint32_t r) -> uint32_t { if constexpr (LOGN == 13) return (cB1 ^ (((r << 1) ^ r) & 31)) + (r << 5); else return swz<LOGN>(lay<LOGN, 1>(t, r)); };
+  auto L2 = [&](uint32_t r) -> uint32_t { if constexpr (LOGN == 13) return cC2 ^ ((r << 1) ^ (r >> 3)); else return swz<LOGN>(lay<LOGN, 2>(t, r)); };
+  auto L3 = [&](uint32_t r) -> uint32_t { if constexpr (LOGN == 13) return (cA3 ^ (r & 1)) + ((r >> 1) << 10); else return swz<LOGN>(lay3<LOGN>(t, r)); };
 
   if (!INV) {
     constexpr int B0 = FWD_IN, B1 = bound_after4(B0), B2 = bound_after4(B1), B3 = bound_after4(B2);

@@ -17,7 +17,8 @@ n = 1 << logn
 B = int(sys.argv[2]) if len(sys.argv) > 2 else (1 << 28) // (8 * n)
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 with avp.VP(spm_rows=B * n // 128, ksk_rows=1, max_log_n=logn) as vp:
-    mods = [avp.nth_prime(logn, i) for i in range(16) for _ in range(B // 16)]
+    P = int(os.environ.get("PRIMES", "16"))                       # limbs per prime = B / P (bench.py quotes N = 2^13 on one prime)
+    mods = [avp.nth_prime(logn, i) for i in range(P) for _ in range(B // P)]
     vp.fill_synthetic(SPM, 0, logn, mods, seed_base=0xA10A + 900000)
     a = vp.read(SPM, 0, n)
     vp.ntt_rows(SPM, 0, 0, logn, mods)

@@ -84,3 +84,32 @@ def test_shipped_default():
     rp, res = patterns(int(m.group(1)))
     # whichever layout ships, the reduction of the inner-product kernel (R*8*64 words per wave, ntt_ks.hip) must fit the region
     assert 2 * 8 * 64 <= 4 * rp
+
+
+def test_single_pass_n8192_closed_form_addresses():
+    """csrc/ntt_single.hip at N = 2^13 addresses its LDS image through closed forms of swz(lay(t, r)) -- a per-lane base XOR a 5-bit
+    constant of the register index, plus the register's own index bits as an immediate -- instead of deriving them per access
+    (round 4: -9 % of the kernel's instructions).  The identities, exhaustively, against the definitions the other sizes use."""
+    LOGN = 13
+    N, T, E = 1 << LOGN, (1 << LOGN) // 16, LOGN - 12
+    swz = lambda e: e ^ ((e >> 4) & 31) ^ ((e >> 5) & 31)
+
+    def lay(K, t, r):
+        P = LOGN - 4 - 4 * K
+        return ((t >> P) << (P + 4)) | (r << P) | (t & ((1 << P) - 1))
+
+    lay3 = lambda t, r: (r >> E) * ((1 << LOGN) >> (4 - E)) + (t << E) + (r & ((1 << E) - 1))
+    src = open(os.path.join(os.path.dirname(HPP), "ntt_single.hip")).read()
+    for text in ("cA0 = t ^ (t >> 4) ^ ((t >> 5) & 15)", "(cA0 ^ ((r & 1) << 4)) + (r << 9)", "(cB1 ^ (((r << 1) ^ r) & 31)) + (r << 5)",
+                 "cC2 ^ ((r << 1) ^ (r >> 3))", "(cA3 ^ (r & 1)) + ((r >> 1) << 10)"):
+        assert text in src, text
+    for t in range(T):
+        cA0 = t ^ (t >> 4) ^ ((t >> 5) & 15)
+        cB1 = (((t >> 5) << 9) | (t & 31)) ^ ((t >> 4) & 1) ^ (((t >> 5) & 1) << 4)
+        cC2 = (((t >> 1) << 5) | (t & 1)) ^ (((t >> 1) & 15) << 1) ^ ((t >> 1) & 31)
+        cA3 = (t << 1) ^ ((t >> 3) & 31) ^ ((t >> 4) & 31)
+        for r in range(16):
+            assert swz(lay(0, t, r)) == (cA0 ^ ((r & 1) << 4)) + (r << 9)
+            assert swz(lay(1, t, r)) == (cB1 ^ (((r << 1) ^ r) & 31)) + (r << 5)
+            assert swz(lay(2, t, r)) == cC2 ^ ((r << 1) ^ (r >> 3))
+            assert swz(lay3(t, r)) == (cA3 ^ (r & 1)) + ((r >> 1) << 10)
