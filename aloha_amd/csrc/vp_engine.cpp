@@ -826,8 +826,16 @@ inline bool overlap(const u64 *a, const u64 *b, size_t n) { return a < b + n && 
 // Device copy of a job array, cached by content: programs repeat, so in steady state a batched
 // launch needs no upload.  Entries are immutable; eviction happens only after a stream sync.
 aloha_status device_blob(aloha_vp *vp, const void *host, size_t bytes, const void **dev) {
-  for (auto &b : vp->blobs)
-    if (b.first.size() == bytes && memcmp(b.first.data(), host, bytes) == 0) { *dev = b.second; return ALOHA_OK; }
+  for (size_t i = 0; i < vp->blobs.size(); i++) {
+    auto &b = vp->blobs[i];
+    if (b.first.size() == bytes && memcmp(b.first.data(), host, bytes) == 0) {
+      *dev = b.second;
+      // least recently USED goes first: a flush hands out several blobs before it launches with them, and a miss among them evicts
+      // the front entry -- which must not be one handed out a moment ago (a hit used to leave the entry where it was)
+      if (i + 1 != vp->blobs.size()) std::rotate(vp->blobs.begin() + i, vp->blobs.begin() + i + 1, vp->blobs.end());
+      return ALOHA_OK;
+    }
+  }
   void *d = nullptr;
   HIPCK(vp, hipMalloc(&d, bytes));
   HIPCK(vp, hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, vp->stream));

@@ -24,10 +24,11 @@ for rnd in range(rounds):
             run = lambda: vp.run(0, src0=0, src1=L * rows, rslt=2 * L * rows)
             assert run() == 0
             vp.sync()
-            x, y = vp.read(SPM, 0, n), vp.read(SPM, L * rows, n)
-            fx, fy = oracle.ntt(x, mods[0]), oracle.ntt(y, mods[0])
-            prod = np.array([(int(u) * int(v)) % mods[0] for u, v in zip(fx, fy)], dtype=np.uint64)
-            assert np.array_equal(vp.read(SPM, 2 * L * rows, n), oracle.intt(prod, mods[0]))
+            o = oracle.OracleVP(spm_rows=3 * L * rows, ksk_rows=1)              # every limb, through the oracle machine on the same program
+            o.write(SPM, 0, vp.read(SPM, 0, 2 * L * n)); o.load_isram(0, programs.assemble(programs.poly_mul(n, mods)))
+            assert o.run(0, src0=0, src1=L * rows, rslt=2 * L * rows) == 0
+            assert np.array_equal(vp.read(SPM, 2 * L * rows, L * n), o.read(SPM, 2 * L * rows, L * n))
+            o.close()
             ts = []
             for blk in range(5):
                 t0 = time.perf_counter()
