@@ -305,8 +305,8 @@ def configs_leg(device: int, budget_s: float = 85.0) -> dict:
             "frac": byb["fused_minimum"] / tb / 1e9 / HBM_PEAK_GBS, "verified": okb}
 
     # -- configs 4 / 5: HMult + relinearisation at L = 24, rotate + key-switch at L = 32 (N = 2^16, hybrid alpha = K = 4) -------
-    def keyswitch(L, op):
-        logn, n, alpha = 16, 1 << 16, 4
+    def keyswitch(L, op, alpha=4):
+        logn, n = 16, 1 << 16
         mods = [avp.nth_prime(logn, i) for i in range(L)]
         specials = [avp.nth_prime(logn, L + k) for k in range(alpha)]
         lo = hybrid.HybridLayout(n, mods, specials, alpha)
@@ -350,6 +350,10 @@ def configs_leg(device: int, budget_s: float = 85.0) -> dict:
 
     out["config4_hmult_relin_n65536_L24"] = keyswitch(24, "multiply")
     out["config5_rotate_keyswitch_n65536_L32"] = keyswitch(32, "rotate")
+    # the digit size is the implementation's choice (BASELINE names the limbs, not the decomposition): alpha = K = 8 -- 3 / 4 digits --
+    # halves the lifted limbs and the key against alpha = 4 at the price of twice the special primes
+    out["config4_hmult_relin_n65536_L24_alpha8"] = keyswitch(24, "multiply", 8)
+    out["config5_rotate_keyswitch_n65536_L32_alpha8"] = keyswitch(32, "rotate", 8)
 
     # -- configs 4 / 5 on the decomposition SURVEY 8d DEFINES them on: one digit per ciphertext prime and ONE special prime -- the
     #    reference's own algorithm (keyswitch.mem:4-43 digits, :46-79 inner products, :80-121 mod-down), generated for L limbs by
