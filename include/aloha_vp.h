@@ -30,6 +30,13 @@
  * REJECTS what the RTL leaves undefined.  Threading: a handle is single-threaded, like the
  * one-instruction-in-flight sequencer (seq_top.v:343-413); internally work is enqueued on a
  * HIP stream, aloha_vp_run may return before completion, aloha_vp_sync / aloha_vp_read block.
+ *
+ * One kernel of the library waits INSIDE its grid: the polynomial product at N = 2^14 as one launch (a loop of
+ * `vle; vntt; vle; vntt; vfqmul.vv; vintt; vse` whose destination is none of its operands).  Its later phases wait for the earlier
+ * ones, which makes progress while every XCD dispatches a queue's workgroups in grid order -- observed on MI355X, not promised by
+ * HIP.  Every wait is bounded (1 s); a launch that gave up is reported as ALOHA_ERR_DEVICE by the next aloha_vp_sync / aloha_vp_read,
+ * its operands are intact, and the handle runs its later products as five ordinary launches.  At most one handle per device has
+ * such a launch in flight; a second handle's products take the five-launch form meanwhile (aloha_vp_stats.product_fallbacks).
  */
 #ifndef ALOHA_VP_H
 #define ALOHA_VP_H
