@@ -51,6 +51,12 @@ ALOHA_DEV u64 mad32_zs(u32 a, u32 b) {
   asm("v_mad_u64_u32 %0, s[94:95], %1, %2, 0" : "=v"(r) : "v"(a), "s"(b) : "s94", "s95");
   return r;
 }
+// c + a as ONE instruction (a 32-bit value added into a 64-bit accumulator: a * 1 + c)
+ALOHA_DEV u64 mad32_one(u32 a, u64 c) {
+  u64 r;
+  asm("v_mad_u64_u32 %0, s[94:95], %1, 1, %2" : "=v"(r) : "v"(a), "v"(c) : "s94", "s95");
+  return r;
+}
 ALOHA_DEV u32 mullo32(u32 a, u32 b) {
   u32 r;
   asm("v_mul_lo_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

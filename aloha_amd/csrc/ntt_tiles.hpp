@@ -70,8 +70,87 @@ __device__ __forceinline__ void sum_pair(u64 (&v)[NV], const SumSrc *__restrict_
     for (int i = 0; i < NV; i++) v[i] += APPROX ? mul_shoup_4q<true>(x1[i], s1, sp1, nq) : shoup_2q_uni(x1[i], s1, sp1, nq);
   }
 }
+// ALOHA_PRO_CHAIN = 1 (round 4, shipped): the <= 4 products of an element on SHARED multiply-add chains -- a*s accumulates over
+// the terms on one 64-bit chain (+ one for the cross terms), the approximate quotients on a third, and quotient * (2^64 - q) is added
+// ONCE: 8 instructions per term + 4 per element instead of 14 per term.  The same words: sum_t (a_t s_t - qhat_t q) is linear in the
+// low 64 bits, every term lies in [0, 4q), four of them below 2^64.  Six live registers per element instead of two, so the tile's
+// 16 elements go in quarters with all terms' loads of a quarter in flight (112 VGPRs, no scratch).  5..8 terms: two such sums, each
+// canonicalised.  Measured on one box, interleaved (profiles/r04_modup_prologue_chain_ab.txt): HMult L = 24 alpha = 4 0.2738 -> 0.2677
+// ms, alpha = 8 0.2500 -> 0.2419; rotate L = 32 alpha = 4 0.3879 -> 0.3834, alpha = 8 0.3427 -> 0.3264.  = 0: rounds 2-3 (two operands
+// at a time over all 16 elements, one reduced product per term).
+#ifndef ALOHA_PRO_CHAIN
+#define ALOHA_PRO_CHAIN 1
+#endif
+template <int NV, class ADDR>
+__device__ __forceinline__ void sum_prologue_chain(u64 (&v)[NV], const SumSrc *__restrict__ ss, const ADDR &addr, u64 q, u64 nq, u32 kc) {
+  const int T = ss->nterms;                                      // (wave-uniform)
+  const u64 c = ss->cst;
+  const u32 n0 = lo32(nq), n1 = hi32(nq);
+#pragma unroll
+  for (int qb = 0; qb < NV / 4; qb++) {
+    u64 res[2];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      if (4 * g >= T) { res[g] = 0; continue; }                  // (wave-uniform)
+      u64 x[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        if (4 * g + t < T) {
+          cgptr_t a = (cgptr_t)ss->a[4 * g + t];
+#pragma unroll
+          for (int e = 0; e < 4; e++) x[t][e] = a[addr(4 * qb + e)];
+        }
+      u64 acc[4], tt[4], Q[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        if (4 * g + t < T) {
+          const u64 s = ss->s[4 * g + t], sp = ss->sp[4 * g + t];
+          const u32 s0 = lo32(s), s1 = hi32(s), p0 = lo32(sp), p1 = hi32(sp);
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const u32 a0 = lo32(x[t][e]), a1 = hi32(x[t][e]);
+            const u32 hc = mulhi32_s(a1, p0), hd = mulhi32_s(a0, p1);
+            if (t == 0) {
+              Q[e] = mad32_s(a1, p1, (u64)hc + hd);
+              tt[e] = mad32_s(a0, s1, mad32_zs(a1, s0));
+              acc[e] = mad32_zs(a0, s0);
+            } else {
+              Q[e] = mad32_s(a1, p1, mad32_one(hd, mad32_one(hc, Q[e])));
+              tt[e] = mad32_s(a0, s1, mad32_s(a1, s0, tt[e]));
+              acc[e] = mad32_s(a0, s0, acc[e]);
+            }
+          }
+        }
+      u64 r[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        u64 t2 = mad32_s(hi32(Q[e]), n0, tt[e]);
+        t2 = mad32_s(lo32(Q[e]), n1, t2);
+        const u64 a2 = mad32_s(lo32(Q[e]), n0, acc[e]);
+        r[e] = pack64(lo32(a2), hi32(a2) + lo32(t2));          // sum of <= 4 products, each in [0, 4q): < 16q
+      }
+      if (g == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[4 * qb + e] = r[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[4 * qb + e] = canon_any(v[4 * qb + e], q, nq, kc) + canon_any(r[e], q, nq, kc);   // < 2q
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const u64 r = canon_any(v[4 * qb + e], q, nq, kc);
+      v[4 * qb + e] = c ? csub_u(r + c, q) : r;                  // (wave-uniform: a basis extension has no constant, the mod-down's has)
+    }
+  }
+}
+
 template <int NV, class ADDR>
 __device__ __forceinline__ void sum_prologue(u64 (&v)[NV], const SumSrc *__restrict__ ss, const ADDR &addr, u64 q, u64 nq, u32 kc) {
+#if ALOHA_PRO_CHAIN
+  sum_prologue_chain<NV>(v, ss, addr, q, nq, kc);
+  return;
+#endif
   const int T = ss->nterms;                                      // (wave-uniform)
   if (T <= 4) {
     sum_pair<true>(v, ss, 0, T > 1, true, addr, nq);
