@@ -84,7 +84,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void nt
   }
   row_fwd_core<UNIA, FWD_MID, false>(v, lds, L, blkA, blkB, pr);
   if (has) {
-    // the first two operands' loads go out together, ahead of the product with the transform
+    // the first two operands' loads go out together, ahead of the product with the transform.  (The three products on shared
+    // multiply-add chains, as in the column pass's prologue: measured in round 4, 0.2672 against 0.2643 ms -- this kernel waits for
+    // memory at three waves per SIMD, its instructions are not what it costs; profiles/r04_ks_kernel_experiments.txt)
     u64 x0[16], x1[16];
     if (nops > 0) {
 #pragma unroll
