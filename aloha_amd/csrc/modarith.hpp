@@ -29,6 +29,25 @@ ALOHA_DEV u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 // nothing reads -- a compiler-allocated dummy can land on an SGPR that a later VALU instruction
 // reads, and the hazard recogniser then pads every such pair with s_nop.
 // "_s" variants take the second factor from an SGPR (wave-uniform twiddle / modulus limbs).
+// ALOHA_PLAIN_MUL = 1 (round 4 experiment): the same helpers as plain C.  On gfx940+ LLVM's hazard recogniser assumes a "dst
+// forwarding" hazard between ANY inline asm and a following instruction that touches one of its registers (the clobbered s[94:95]
+// included) and pads with `s_nop 0`: ~25 % of the instruction stream of every transform kernel (452 per 1316 VALU instructions in the
+// headline row kernel).  The compiler's own v_mad_u64_u32 gets no padding (tools/ubench_nop.hip); the price is its instruction
+// selection: the cross-term chain narrows to v_mul_lo_u32 + v_add3_u32 (~+11 % VALU instructions per butterfly).
+#ifndef ALOHA_PLAIN_MUL
+#define ALOHA_PLAIN_MUL 0
+#endif
+#if ALOHA_PLAIN_MUL
+ALOHA_DEV u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+ALOHA_DEV u64 mad32_s(u32 a, u32 b, u64 c) { return (u64)a * b + c; }
+ALOHA_DEV u64 mad32_z(u32 a, u32 b) { return (u64)a * b; }
+ALOHA_DEV u64 mad32_zs(u32 a, u32 b) { return (u64)a * b; }
+ALOHA_DEV u64 mad32_one(u32 a, u64 c) { return c + a; }
+ALOHA_DEV u32 mullo32(u32 a, u32 b) { return a * b; }
+ALOHA_DEV u32 mullo32_s(u32 a, u32 b) { return a * b; }
+ALOHA_DEV u32 mulhi32(u32 a, u32 b) { return __umulhi(a, b); }
+ALOHA_DEV u32 mulhi32_s(u32 a, u32 b) { return __umulhi(a, b); }
+#else
 ALOHA_DEV u64 mad32(u32 a, u32 b, u64 c) {
   u64 r;
   asm("v_mad_u64_u32 %0, s[94:95], %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "s94", "s95");
@@ -78,6 +97,8 @@ ALOHA_DEV u32 mulhi32_s(u32 a, u32 b) {
   return r;
 }
 
+#endif
+
 // ---- canonicalisation ------------------------------------------------------------------
 ALOHA_DEV u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }          // [0,2q) -> [0,q)
 ALOHA_DEV u64 addmod(u64 a, u64 b, u64 q) { return csub(a + b, q); }        // a,b < q
@@ -123,7 +144,11 @@ ALOHA_DEV u64 mullo2_acc(u64 a, u64 w, u64 b, u64 nq) {
   u64 acc = UNI ? mad32_zs(a0, w0) : mad32_z(a0, w0);
   acc = mad32_s(b0, n0, acc);
   u32 h = hi32(acc);
+#if ALOHA_PLAIN_MUL
+  h += lo32(t);
+#else
   asm("v_add_u32 %0, %0, %1" : "+v"(h) : "v"(lo32(t)));
+#endif
   return pack64(lo32(acc), h);
 }
 
@@ -172,7 +197,11 @@ ALOHA_DEV u64 shoup_fold_add(u64 X, u64 a, u64 w, u64 qhat, u64 nq) {
   u64 acc = UNI ? mad32_s(a0, w0, X) : mad32(a0, w0, X);
   acc = mad32_s(b0, n0, acc);
   u32 h = hi32(acc);
+#if ALOHA_PLAIN_MUL
+  h += lo32(t);
+#else
   asm("v_add_u32 %0, %0, %1" : "+v"(h) : "v"(lo32(t)));          // pinned: as C, LLVM widens this to a 64-bit add plus moves
+#endif
   return pack64(lo32(acc), h);
 #else
   u32 x0 = UNI ? mullo32_s(a1, w0) : mullo32(a1, w0);
