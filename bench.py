@@ -41,7 +41,7 @@ import torch  # noqa: E402
 LOGN = 16
 N = 1 << LOGN
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_SUMMARY = "r03_pmc_summary.json"     # written by tools/collect_pmc.sh; its "commit" field says for which kernels
+PMC_SUMMARY = "r04_pmc_summary.json"     # written by tools/collect_pmc.sh; its "commit" field says for which kernels
 
 
 def pmc_summary():

@@ -13,7 +13,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_IN
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
            "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   name=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-settle \
+  rocprofv3 --pmc $grp --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-settle --no-configs \
     > "$OUT/$name.log" 2>&1
 done
 # the snapshot on the box has no .git: the caller passes the commit (ALOHA_COMMIT=$(git rev-parse --short HEAD) in front of gpurun's command)
