@@ -334,6 +334,12 @@ __device__ __forceinline__ uint32_t swh(uint32_t y) { return y ^ ((y >> 3) & 31)
 __device__ __forceinline__ uint32_t lay1(uint32_t l, uint32_t r) { return (r << 6) | l; }                               // registers = bits 8..6
 __device__ __forceinline__ uint32_t lay2(uint32_t l, uint32_t r) { return ((l >> 3) << 6) | (r << 3) | (l & 7); }      // registers = bits 5..3
 __device__ __forceinline__ uint32_t lay3(uint32_t l, uint32_t r) { return (l << 3) | r; }                              // registers = bits 2..0
+// swh(layK(l, r)) in CLOSED FORM (round 4): the swizzle touches bits 0..4 only, so the LDS word is a per-lane base XOR a small
+// constant of the register index, plus -- for lay1 -- the register's own bits as an instruction immediate: 0 / 1 / 1 vector
+// instructions per access where the compiler derived ~2.4 from the composition (tests/test_lds_layout.py checks the identities)
+__device__ __forceinline__ uint32_t sw1(uint32_t l, uint32_t r) { return ((l ^ (l >> 3)) ^ ((r & 3) << 3)) + (r << 6); }
+__device__ __forceinline__ uint32_t sw2(uint32_t l, uint32_t r) { return ((((l >> 3) << 6) | (l & 7)) ^ (((l >> 3) & 3) << 3)) ^ (r * 9); }
+__device__ __forceinline__ uint32_t sw3(uint32_t l, uint32_t r) { return ((l << 3) ^ (l & 31)) ^ r; }
 
 struct TwRow {                     // entries 2^(S0+ss) + a*2^ss + g of the plain (w, w') table
   ctw_t tab;

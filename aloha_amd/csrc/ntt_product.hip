@@ -146,19 +146,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     fwd_radix8<true, B4>(u, TwRow{ftab, 32, R}, q, nq);                                   // stages 5..7: y bits 8..6
     PROD_STAMP(3);
 #pragma unroll
-    for (int r = 0; r < 8; r++) my[swh(lay1(lane, r))] = u[r];
+    for (int r = 0; r < 8; r++) my[sw1(lane, r)] = u[r];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) u[r] = my[swh(lay2(lane, r))];
+    for (int r = 0; r < 8; r++) u[r] = my[sw2(lane, r)];
     PROD_STAMP(4);
     fwd_radix8<false, B7>(u, TwReg7{tw2}, q, nq);                                          // stages 8..10: y bits 5..3
     PROD_STAMP(5);
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) my[swh(lay2(lane, r))] = u[r];
+    for (int r = 0; r < 8; r++) my[sw2(lane, r)] = u[r];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) u[r] = my[swh(lay3(lane, r))];
+    for (int r = 0; r < 8; r++) u[r] = my[sw3(lane, r)];
     PROD_STAMP(6);
     fwd_radix8<false, B10>(u, TwReg7{tw3}, q, nq);                                         // stages 11..13: y bits 2..0
     PROD_STAMP(7);
@@ -184,19 +184,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       PROD_STAMP(11);
       wave_lds_fence();
 #pragma unroll
-      for (int r = 0; r < 8; r++) my[swh(lay3(lane, r))] = u[r];
+      for (int r = 0; r < 8; r++) my[sw3(lane, r)] = u[r];
       wave_lds_fence();
 #pragma unroll
-      for (int r = 0; r < 8; r++) u[r] = my[swh(lay2(lane, r))];
+      for (int r = 0; r < 8; r++) u[r] = my[sw2(lane, r)];
       PROD_STAMP(12);
       inv_radix8<false>(u, TwReg7{itw2}, q, nq);                                            // stages 10..8
       PROD_STAMP(13);
       wave_lds_fence();
 #pragma unroll
-      for (int r = 0; r < 8; r++) my[swh(lay2(lane, r))] = u[r];
+      for (int r = 0; r < 8; r++) my[sw2(lane, r)] = u[r];
       wave_lds_fence();
 #pragma unroll
-      for (int r = 0; r < 8; r++) u[r] = my[swh(lay1(lane, r))];
+      for (int r = 0; r < 8; r++) u[r] = my[sw1(lane, r)];
       inv_radix8<true>(u, TwRow{itab, 32, R}, q, nq);                                       // stages 7..5
       PROD_STAMP(14);
       // stage 4: the halves meet

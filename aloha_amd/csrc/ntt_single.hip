@@ -265,23 +265,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     for (int r = 0; r < 8; r++) lds[r * 512 + swh(t)] = v[r];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = my[swh(lay1(l, r))];
+    for (int r = 0; r < 8; r++) v[r] = my[sw1(l, r)];
     fwd_radix8<true, B1>(v, TwRow{tab, 8, w}, q, nq);                                    // stages 3..5
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) my[swh(lay1(l, r))] = v[r];
+    for (int r = 0; r < 8; r++) my[sw1(l, r)] = v[r];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = my[swh(lay2(l, r))];
+    for (int r = 0; r < 8; r++) v[r] = my[sw2(l, r)];
     fwd_radix8<false, B2>(v, TwReg7{tw2}, q, nq);                                        // stages 6..8
     tw_t tw3[7];                                                 // (requested only now: with tw2 alive as well the kernel spills at 80 VGPRs)
     preload7(tw3, tab, 512, w * 64 + l);
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) my[swh(lay2(l, r))] = v[r];
+    for (int r = 0; r < 8; r++) my[sw2(l, r)] = v[r];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = my[swh(lay3(l, r))];
+    for (int r = 0; r < 8; r++) v[r] = my[sw3(l, r)];
     fwd_radix8<false, B3>(v, TwReg7{tw3}, q, nq);                                        // stages 9..11
     const u32 kc = (u32)pr->m.kc;
 #pragma unroll
@@ -290,39 +290,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // 64 partial lines per instruction -- measured at HALF the kernel's speed)
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) my[swh(lay3(l, r))] = v[r];
+    for (int r = 0; r < 8; r++) my[sw3(l, r)] = v[r];
     wave_lds_fence();
     gptr_t o = dst + w * 512 + l;
 #pragma unroll
-    for (int r = 0; r < 8; r++) st_stream(o + r * 64, my[swh(lay1(l, r))]);
+    for (int r = 0; r < 8; r++) st_stream(o + r * 64, my[sw1(l, r)]);
   } else {
     tw_t tw3[7], tw2[7];
     preload7(tw3, tab, 512, w * 64 + l);
     cgptr_t i = src + w * 512 + l;
 #pragma unroll
-    for (int r = 0; r < 8; r++) my[swh(lay1(l, r))] = ld_stream(i + r * 64);               // < 2^60 < 4q; lane-contiguous loads
+    for (int r = 0; r < 8; r++) my[sw1(l, r)] = ld_stream(i + r * 64);               // < 2^60 < 4q; lane-contiguous loads
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = my[swh(lay3(l, r))];
+    for (int r = 0; r < 8; r++) v[r] = my[sw3(l, r)];
     wave_lds_fence();
     preload7(tw2, tab, 64, w * 8 + (l >> 3));
     inv_radix8<false>(v, TwReg7{tw3}, q, nq);                                              // stages 11..9
 #pragma unroll
-    for (int r = 0; r < 8; r++) my[swh(lay3(l, r))] = v[r];
+    for (int r = 0; r < 8; r++) my[sw3(l, r)] = v[r];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = my[swh(lay2(l, r))];
+    for (int r = 0; r < 8; r++) v[r] = my[sw2(l, r)];
     inv_radix8<false>(v, TwReg7{tw2}, q, nq);                                              // stages 8..6
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) my[swh(lay2(l, r))] = v[r];
+    for (int r = 0; r < 8; r++) my[sw2(l, r)] = v[r];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = my[swh(lay1(l, r))];
+    for (int r = 0; r < 8; r++) v[r] = my[sw1(l, r)];
     inv_radix8<true>(v, TwRow{tab, 8, w}, q, nq);                                          // stages 5..3
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; r++) my[swh(lay1(l, r))] = v[r];
+    for (int r = 0; r < 8; r++) my[sw1(l, r)] = v[r];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; r++) v[r] = lds[r * 512 + swh(t)];

@@ -113,3 +113,17 @@ def test_single_pass_n8192_closed_form_addresses():
             assert swz(lay(1, t, r)) == (cB1 ^ (((r << 1) ^ r) & 31)) + (r << 5)
             assert swz(lay(2, t, r)) == cC2 ^ ((r << 1) ^ (r >> 3))
             assert swz(lay3(t, r)) == (cA3 ^ (r & 1)) + ((r >> 1) << 10)
+
+
+def test_half_row_closed_form_addresses():
+    """csrc/ntt_device.hpp: sw1 / sw2 / sw3 are swh(lay1 / lay2 / lay3) in closed form (the radix-8 single-pass kernel at N = 2^12 and
+    the one-launch polynomial product address their half rows through them)."""
+    swh = lambda y: y ^ ((y >> 3) & 31)
+    src = open(os.path.join(os.path.dirname(HPP), "ntt_device.hpp")).read()
+    for text in ("return ((l ^ (l >> 3)) ^ ((r & 3) << 3)) + (r << 6);", "^ (r * 9);", "return ((l << 3) ^ (l & 31)) ^ r;"):
+        assert text in src, text
+    for l in range(64):
+        for r in range(8):
+            assert swh((r << 6) | l) == ((l ^ (l >> 3)) ^ ((r & 3) << 3)) + (r << 6)
+            assert swh(((l >> 3) << 6) | (r << 3) | (l & 7)) == ((((l >> 3) << 6) | (l & 7)) ^ (((l >> 3) & 3) << 3)) ^ (r * 9)
+            assert swh((l << 3) | r) == ((l << 3) ^ (l & 31)) ^ r
