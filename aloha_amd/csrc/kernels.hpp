@@ -167,6 +167,8 @@ struct PrimeDev {
   ModCtx m;
   TwiddleDev tw;
 };
+constexpr uint32_t kPrimeTableEntries = 4096;   // entries of the device table of PrimeDev (the engine's twiddle-set cache indexes it)
+constexpr uint32_t kTileTraceWords = 1u << 17;  // variant builds with -DALOHA_TILE_TRACE: clock stamps behind the table (ntt_tiles.hpp)
 
 struct TileDesc {        // one row-pass tile of ntt_tile.hip
   uint32_t first_limb;   // first limb of the bundle (same prime, consecutive jobs)

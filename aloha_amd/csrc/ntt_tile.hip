@@ -61,6 +61,7 @@ template <bool INV, bool FIRST, bool LAST, bool SC = false>     // SC: jobs may 
 __global__ __launch_bounds__(256) void ntt_col_kernel(const LimbJob *__restrict__ jobs, const PrimeDev *__restrict__ primes, uint32_t count) {
   __shared__ u64 sdata[LINES * PITCH];
   const int tid = threadIdx.x;
+  TILE_STAMP(primes, 0, 7);
   // XCD-affine tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share
   // one), so limb = 8*(b/128) + b%8, column group = (b/8)%16 puts the 16 column groups of a
   // limb -- which together cover each 2 KiB row -- on ONE XCD's L2.  Measured on the bare
@@ -198,8 +199,10 @@ __device__ __forceinline__ void row_tile(u64 *lds, const LimbJob *__restrict__ j
   gptr_t dst = (gptr_t)jA.dst + ((size_t)rowA << 8) + L.plA;
 
   u64 v[16];
+  ROW_STAMP(pr, j0.prime, 0);
 #pragma unroll
   for (int kk = 0; kk < 16; kk++) v[kk] = ld_stream(&src[16 * kk]);
+  ROW_STAMP_VM(pr, j0.prime, 1);
   if (!INV) {
     row_fwd_core<UNIA, FIRST ? FWD_IN : FWD_MID, LAST>(v, lds, L, blkA, blkB, pr);
   } else {
@@ -210,8 +213,11 @@ __device__ __forceinline__ void row_tile(u64 *lds, const LimbJob *__restrict__ j
       for (int kk = 0; kk < 16; kk++) v[kk] = scale_canon(v[kk], ni, nip, q, nq);
     }
   }
+  ROW_STAMP(pr, j0.prime, 4);
 #pragma unroll
   for (int kk = 0; kk < 16; kk++) st_stream(&dst[16 * kk], v[kk]);
+  ROW_STAMP(pr, j0.prime, 5);
+  ROW_STAMP_VM(pr, j0.prime, 6);
 }
 
 // (the inverse instantiations settle at 100-134 VGPRs, 3-4 waves per SIMD; holding them to 96 costs 28 B of scratch and 2 %)
@@ -223,6 +229,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void nt
                                                                                               const PrimeDev *__restrict__ primes,
                                                                                               const TileDesc *__restrict__ tiles) {
   __shared__ u64 sdata[4 * RP];
+  ROW_STAMP(primes, 0, 7);
   row_tile<INV, UNIA, FIRST, LAST>(sdata, jobs, primes, tiles[blockIdx.x >> 2], blockIdx.x & 3, threadIdx.x);
 }
 

@@ -39,6 +39,27 @@ constexpr int kInvColPreload = 15;   // inverse column pass: all 15 of the first
 constexpr int kRowPreload = ALOHA_ROW_PRELOAD;   // forward row pass: sub-stages 0..2 of the second step before the first step
 constexpr int kInvRowPreload = 15;   // inverse row pass (0 / 12 / 15 = 2.44 / 2.45 / 2.48 M)
 
+// Variant builds with -DALOHA_TILE_TRACE: the first thread of every workgroup leaves constant-rate clock stamps (100 MHz) of its
+// steps behind the prime table (kernels.hpp: kTileTraceWords): where the time of a SMALL launch goes -- one tile's latency, which
+// is what the key-switch's 8- and 24-limb transforms cost (tests/perf/tile_trace.py).  _VM: once the loads have landed.
+#ifdef ALOHA_TILE_TRACE
+// (column kernels stamp workgroups [0, 2048) of the buffer, row kernels [2048, 8192): both passes of one transform stay readable)
+#define TILE_STAMP_AT(prime_ptr, prime_idx, first, count, slot)                                                                 \
+  do {                                                                                                                           \
+    if (threadIdx.x == 0 && blockIdx.x < (count))                                                                                \
+      ((u64 *)((prime_ptr) - (prime_idx) + kPrimeTableEntries))[(size_t)((first) + blockIdx.x) * 16 + (slot)] = wall_clock64();   \
+  } while (0)
+#define TILE_STAMP(prime_ptr, prime_idx, slot) TILE_STAMP_AT(prime_ptr, prime_idx, 0, 2048, slot)
+#define ROW_STAMP(prime_ptr, prime_idx, slot) TILE_STAMP_AT(prime_ptr, prime_idx, 2048, 6144, slot)
+#define TILE_STAMP_VM(prime_ptr, prime_idx, slot) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TILE_STAMP(prime_ptr, prime_idx, slot); } while (0)
+#define ROW_STAMP_VM(prime_ptr, prime_idx, slot) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ROW_STAMP(prime_ptr, prime_idx, slot); } while (0)
+#else
+#define TILE_STAMP(prime_ptr, prime_idx, slot) do { } while (0)
+#define TILE_STAMP_VM(prime_ptr, prime_idx, slot) do { } while (0)
+#define ROW_STAMP(prime_ptr, prime_idx, slot) do { } while (0)
+#define ROW_STAMP_VM(prime_ptr, prime_idx, slot) do { } while (0)
+#endif
+
 // ---- scalar-sum prologue of a forward column tile ------------------------------------------------------------------
 // The limb to transform is not in memory: it is  sum_t a_t[i] * s_t + cst  (mod q) over <= kSumTerms memory operands (a
 // basis conversion: keyswitch.mem:9-14,:29-34,:86-91 are the reference's one-operand cases).  <= 4 terms: approximate
@@ -180,6 +201,7 @@ __device__ __forceinline__ void col_tile_fwd(u64 *sdata, const LimbJob &jb, cons
   const uint32_t offA = (slow << 8) + col, offB = (slow << 12) + col;     // 32-bit lane offsets
   u64 v[16];
   constexpr int BIN = FIRST ? FWD_IN : FWD_MID;
+  TILE_STAMP(pr, jb.prime, 0);
   if (PRO && jb.pro) {                                                    // (workgroup-uniform)
     const uint32_t base = cg * 16 + offA;
     sum_prologue<16>(v, sums + (jb.pro - 1), [&](int kk) { return base + ((uint32_t)(16 * kk) << 8); }, q, nq, (u32)pr->m.kc);
@@ -198,16 +220,22 @@ __device__ __forceinline__ void col_tile_fwd(u64 *sdata, const LimbJob &jb, cons
       twb[(1 << ss) - 1 + g].w = p->w;
       twb[(1 << ss) - 1 + g].wp = p->wp;
     }
+  TILE_STAMP_VM(pr, jb.prime, 1);
   fwd_radix16<true, BIN>(v, TwStepA{blk}, q, nq);
+  TILE_STAMP(pr, jb.prime, 2);
 #pragma unroll
   for (int kk = 0; kk < 16; kk++) sdata[col * PITCH + slow + 16 * kk] = v[kk];
   __syncthreads();
 #pragma unroll
   for (int jj = 0; jj < 16; jj++) v[jj] = sdata[col * PITCH + 16 * slow + jj];
+  TILE_STAMP(pr, jb.prime, 3);
   fwd_radix16<false, bound_after4(BIN)>(v, TwStepReg{twb}, q, nq);
+  TILE_STAMP(pr, jb.prime, 4);
 #pragma unroll
   for (int jj = 0; jj < 16; jj++)
     st_stream(&(dst + ((size_t)jj << 8))[offB], LAST ? canon_any(v[jj], q, nq, (u32)pr->m.kc) : v[jj]);
+  TILE_STAMP(pr, jb.prime, 5);
+  TILE_STAMP_VM(pr, jb.prime, 6);
 }
 
 template <bool FIRST, bool LAST, bool SC>
@@ -220,6 +248,7 @@ __device__ __forceinline__ void col_tile_inv(u64 *sdata, const LimbJob &jb, cons
   const uint32_t offA = (slow << 8) + col, offB = (slow << 12) + col;     // 32-bit lane offsets
   u64 v[16];
   tw_t twb[15];
+  TILE_STAMP(pr, jb.prime, 0);
 #pragma unroll
   for (int ss = 0; ss < 4; ss++)
 #pragma unroll
@@ -231,14 +260,18 @@ __device__ __forceinline__ void col_tile_inv(u64 *sdata, const LimbJob &jb, cons
       }
 #pragma unroll
   for (int jj = 0; jj < 16; jj++) v[jj] = ld_stream(&(src + ((size_t)jj << 8))[offB]);
+  TILE_STAMP_VM(pr, jb.prime, 1);
   inv_radix16<false, FIRST ? INV_IN : INV_MID, false>(v, TwStepMixHi<kInvColPreload>{twb, blk, (int)slow}, q, nq);
+  TILE_STAMP(pr, jb.prime, 2);
 #pragma unroll
   for (int jj = 0; jj < 16; jj++) sdata[col * PITCH + 16 * slow + jj] = v[jj];
   __syncthreads();
 #pragma unroll
   for (int kk = 0; kk < 16; kk++) v[kk] = sdata[col * PITCH + slow + 16 * kk];
+  TILE_STAMP(pr, jb.prime, 3);
   const LastScale ls = last_scale<LAST && SC>(jbp, pr);
   inv_radix16<true, INV_MID, LAST>(v, TwStepA{blk}, q, nq, ls.w, ls.ni, ls.nip);
+  TILE_STAMP(pr, jb.prime, 4);
   const uint32_t zk = (LAST && SC) ? jbp->zk : 0, zkinv = (LAST && SC) ? jbp->zkinv : 0;   // (wave-uniform)
 #pragma unroll
   for (int kk = 0; kk < 16; kk++) {
@@ -249,6 +282,8 @@ __device__ __forceinline__ void col_tile_inv(u64 *sdata, const LimbJob &jb, cons
     }
     st_stream(&(dst + ((size_t)(16 * kk) << 8))[offA], r);
   }
+  TILE_STAMP(pr, jb.prime, 5);
+  TILE_STAMP_VM(pr, jb.prime, 6);
 }
 
 // ---- row pass: 256 contiguous points per line, 4 lines per WAVE ------------------------------------------------

@@ -42,7 +42,7 @@ typedef unsigned long long u64;
 namespace {
 
 constexpr uint32_t kLanes = 128;
-constexpr uint32_t kMaxPrimes = 4096;
+constexpr uint32_t kMaxPrimes = aloha::k::kPrimeTableEntries;
 
 struct PrimeSlot {
   uint64_t q = 0;
@@ -636,7 +636,11 @@ aloha_status aloha_vp_create(const aloha_vp_config *cfg, aloha_vp **out) {
   if (hipMalloc(&vp->d_ksk, (vp->ksk_rows ? vp->ksk_rows : 1) * (size_t)ALOHA_ROW_BYTES) != hipSuccess) return bail("hipMalloc(ksk)");
   if (hipMalloc(&vp->d_vreg, vreg_bytes) != hipSuccess) return bail("hipMalloc(vreg)");
   if (hipMalloc(&vp->d_scratch, (size_t)8 << vp->max_logn) != hipSuccess) return bail("hipMalloc(scratch)");
+#ifdef ALOHA_TILE_TRACE
+  if (hipMalloc(&vp->d_primes, kMaxPrimes * sizeof(PrimeDev) + aloha::k::kTileTraceWords * 8) != hipSuccess) return bail("hipMalloc(primes)");
+#else
   if (hipMalloc(&vp->d_primes, kMaxPrimes * sizeof(PrimeDev)) != hipSuccess) return bail("hipMalloc(primes)");
+#endif
 #ifdef ALOHA_EXPERIMENTS
   if (hipMalloc(&vp->d_fused_status, 4) != hipSuccess) return bail("hipMalloc(status)");
   if (hipMemsetAsync(vp->d_fused_status, 0, 4, vp->stream) != hipSuccess) return bail("memset");
@@ -755,6 +759,17 @@ aloha_status aloha_vp_debug_product_trace(aloha_vp *vp, void *dst, uint64_t byte
   if (!vp || !dst || !vp->d_prod_work || bytes > (1u << 20)) return ALOHA_ERR_ARG;
   DeviceGuard dev_guard(vp);
   HIPCK(vp, hipMemcpyAsync(dst, vp->d_prod_work + aloha::k::poly_product_work_words(), bytes, hipMemcpyDeviceToHost, vp->stream));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
+  return ALOHA_OK;
+}
+#endif
+
+#ifdef ALOHA_TILE_TRACE
+// variant builds with -DALOHA_TILE_TRACE: the clock stamps the tile kernels left behind the prime table (tests/perf/tile_trace.py)
+aloha_status aloha_vp_debug_tile_trace(aloha_vp *vp, void *dst, uint64_t bytes) {
+  if (!vp || !dst || bytes > aloha::k::kTileTraceWords * 8ull) return ALOHA_ERR_ARG;
+  DeviceGuard dev_guard(vp);
+  HIPCK(vp, hipMemcpyAsync(dst, vp->d_primes + kMaxPrimes, bytes, hipMemcpyDeviceToHost, vp->stream));
   HIPCK(vp, hipStreamSynchronize(vp->stream));
   return ALOHA_OK;
 }
