@@ -120,12 +120,21 @@ ALOHA_DEV u64 mul_shoup_2q(u64 a, u64 w, u64 wp, u64 q) {
 // half are dropped, so qhat is short by at most 2 and the result lies in [0, 4q) (< 2^62).
 // 9 multiplier issues in all (3 for qhat, 6 for the two low products), no carry chains.
 // UNI = the constant (w, wp) is wave-uniform and lives in SGPRs.
+// ALOHA_QHAT_ADD = 1: the sums of a 32-bit term into a 64-bit one inside the quotients as C additions (a zero-extension move plus
+// a 64-bit add each); 0 (shipped, round 4): as ONE multiply-add by 1 (mad32_one) -- -5 % VALU instructions in every transform kernel.
+#ifndef ALOHA_QHAT_ADD
+#define ALOHA_QHAT_ADD 0
+#endif
 template <bool UNI>
 ALOHA_DEV u64 shoup_qhat_approx(u64 a, u64 wp) {
   u32 a0 = lo32(a), a1 = hi32(a), w0 = lo32(wp), w1 = hi32(wp);
   u32 c = UNI ? mulhi32_s(a1, w0) : mulhi32(a1, w0);
   u32 d = UNI ? mulhi32_s(a0, w1) : mulhi32(a0, w1);
+#if ALOHA_QHAT_ADD
   u64 cd = (u64)c + d;
+#else
+  u64 cd = mad32_one(c, (u64)d);                                 // c + d as one multiply-add (c * 1 + {d, 0}): no zero-extension move for c
+#endif
   return UNI ? mad32_s(a1, w1, cd) : mad32(a1, w1, cd);
 }
 
@@ -174,7 +183,11 @@ ALOHA_DEV u64 shoup_qhat_exact(u64 a, u64 wp) {
   u64 m1 = UNI ? mad32_s(a1, w0, (u64)t) : mad32(a1, w0, (u64)t);                 // < 2^64
   u64 m2 = UNI ? mad32_s(a0, w1, (u64)lo32(m1)) : mad32(a0, w1, (u64)lo32(m1));   // < 2^64
   u64 m3 = UNI ? mad32_s(a1, w1, (u64)hi32(m1)) : mad32(a1, w1, (u64)hi32(m1));   // < 2^64
+#if ALOHA_QHAT_ADD
   return m3 + hi32(m2);
+#else
+  return mad32_one(hi32(m2), m3);
+#endif
 }
 
 // out0 = X + (a*w + qhat*nq)  (mod 2^64): the X + T sum rides on the accumulator chain.
@@ -299,7 +312,12 @@ ALOHA_DEV u64 mulmod_lazy_2q(u64 a, u64 b, u64 nq, u64 mu) {
   const u64 m1 = mad32(a0, b1, (u64)hi32(p00));                 // < 2^64: (2^32-1)^2 + 2^32 - 1
   const u64 m2 = mad32(a1, b0, (u64)lo32(m1));
   const u64 m3 = mad32(a1, b1, (u64)hi32(m1));
-  const u64 zh = m3 + hi32(m2), zl = pack64(lo32(p00), lo32(m2));
+#if ALOHA_QHAT_ADD
+  const u64 zh = m3 + hi32(m2);
+#else
+  const u64 zh = mad32_one(hi32(m2), m3);
+#endif
+  const u64 zl = pack64(lo32(p00), lo32(m2));
   const u64 x1 = (zh << 7) | (zl >> 57);
   const u64 qhat = shoup_qhat_exact<true>(x1, mu);              // floor(x1 * mu / 2^64)
   const u64 acc = mad32_s(lo32(qhat), lo32(nq), zl);            // zl + qhat * nq  (mod 2^64)  ==  zl - qhat * q
