@@ -33,6 +33,8 @@ for i, seed in enumerate(range(first, first + count)):
             bad.append((name, seed, repr(e)[:200]))
     if i % 10 == 9:
         print(f"{i + 1} seeds, {len(bad)} failures, {time.time() - t0:.0f} s", flush=True)
+st = engine.stats()
+print("shared engine:", {k: st[k] for k in ("flow_runs", "kernel_launches", "product_fallbacks") if k in st})
 engine.close()
 print("failures:", bad)
 sys.exit(1 if bad else 0)
