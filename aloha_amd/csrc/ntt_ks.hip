@@ -204,9 +204,10 @@ __device__ __forceinline__ void products_chunk(const u64 (&v)[16], int m, cgptr_
 // key, multiply -- and a key-switch has few groups, so at S = 1 the kernel's time was one wave's latency (the same ~100 us for
 // 18 groups as for 28); S = 2 halves the chain and doubles the waves.
 template <int R, int S>
-__global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(R == 2 ? 4 : 3, R == 2 ? 4 : 3))) void ntt_rowdot_kernel(
+__global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(R == 4 ? 3 : 4, R == 4 ? 3 : 4))) void ntt_rowdot_kernel(
     const RowDotGroup *__restrict__ groups, const PrimeDev *__restrict__ primes) {
-  constexpr int DSH = R == 4 ? 2 : 1, DPT = 4 / R;               // remainder tiles: DPT digits x R rows
+  static_assert(R == 1 || R == 2 || R == 4, "rows per wave");
+  constexpr int DSH = R == 4 ? 2 : R == 2 ? 1 : 0, DPT = 4 / R;  // remainder tiles: DPT digits x R rows
   constexpr int PRE = R == 2 ? 0 : 3;                            // second-step twiddles issued early (registers against latency)
   constexpr uint32_t WPG = 256 / R;                              // workgroups per group
   __shared__ u64 lds_all[S * 4 * RP];
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(R == 2 ?
       const bool transformed = b < nquad + ntr;
       const uint32_t d0 = transformed ? 4 * nquad + (b - nquad) * DPT : nt + (b - nquad - ntr) * DPT;
       const uint32_t end = transformed ? nt : nt + np;          // a tile holds digits of one kind
-      const uint32_t d = d0 + (L.lwA >> (R == 4 ? 2 : 1));      // the lane's digit (A mapping)
+      const uint32_t d = d0 + (L.lwA >> DSH);                   // the lane's digit (A mapping)
       const bool live = R == 4 ? true : d < end;                // (R = 4: one digit per tile, every line has it)
       const uint32_t dd = live ? d : d0;                         // (idle lines read the first digit's rows: defined data, zero weight)
       cgptr_t src = (cgptr_t)g->x[dd] + offP;
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(R == 2 ?
       if (transformed) {
 #pragma unroll
         for (int kk = 0; kk < 16; kk++) v[kk] = ld_stream(&src[16 * kk]);
-        row_fwd_core<false, FWD_MID, true, PRE, (R == 2 ? 7 : 3)>(v, lds, L, blkA, blkB, pr);
+        if constexpr (R == 1) row_fwd_core<true, FWD_MID, true, PRE>(v, lds, L, blkA, blkA, pr);   // (one row: one block for the wave)
+        else row_fwd_core<false, FWD_MID, true, PRE, (R == 2 ? 7 : 3)>(v, lds, L, blkA, blkB, pr);
         gptr_t xo = (gptr_t)g->xout[dd];
         if (live && xo) {
 #pragma unroll
@@ -395,7 +397,14 @@ hipError_t ntt_fwd16_rowdot(hipStream_t st, const RowDotGroup *d_groups, uint32_
   static const int forced_split = getenv("ALOHA_ROWDOT_SPLIT") ? atoi(getenv("ALOHA_ROWDOT_SPLIT")) : 0;
   const bool two = forced ? forced == 2 : ngroups < 96;
   const bool split = forced_split ? forced_split == 2 : ngroups < 48;          // (S = 4, round 4: 0.292 against 0.271 ms; S = 1 equals S = 2 by now: profiles/r04_ks_kernel_experiments.txt)
-  if (two && split) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 2>), dim3(ngroups * 128), dim3(128), 0, st, d_groups, d_primes);
+  // very few groups (a rank's share of a key-switch spread over 8 GPUs: 3-5): ONE row per wave -- at two rows the launch is one
+  // wave per SIMD and its time one wave's chain of tiles; half the chain on twice the waves (rank 0's share at W = 8: HMult L = 24
+  // 0.1027 -> 0.0978 ms, rotate L = 32 0.1164 -> 0.1056; at W = 4, 7 and 9 groups: -2 % and -4 %; at 14 groups and more it loses on the
+  // HMult (5 transformed digits: three tiles per row instead of two) and is within the noise on the rotate; four waves per row
+  // instead of two, or one: no better -- profiles/r04_w8_share_rowdot_rows.txt)
+  const bool one = forced ? forced == 1 : ngroups <= 10;
+  if (one) hipLaunchKernelGGL((ntt_rowdot_kernel<1, 2>), dim3(ngroups * 256), dim3(128), 0, st, d_groups, d_primes);
+  else if (two && split) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 2>), dim3(ngroups * 128), dim3(128), 0, st, d_groups, d_primes);
   else if (two) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 1>), dim3(ngroups * 128), dim3(64), 0, st, d_groups, d_primes);
   else hipLaunchKernelGGL((ntt_rowdot_kernel<4, 1>), dim3(ngroups * 64), dim3(64), 0, st, d_groups, d_primes);
   if (launches) ++*launches;

@@ -53,6 +53,8 @@ def _run(vp, mods, specials, alpha, ct, op, batch=1, hint=True):
     (6, 2, 2, 1),      # dnum 3: two transformed digits + the own one per ciphertext modulus, three per special prime
     (9, 1, 1, 1),      # the reference's decomposition: 8 transformed digits (two groups of four) + 1, and 9 = 2 x 4 + 1
     (10, 2, 2, 2),     # dnum 5: exactly four transformed + own; five under the special primes; two ciphertexts per call
+    (7, 1, 1, 1),      # 8 groups: the one-row-per-wave shape of the inner-product kernel (a rank's share at W = 8) on a group of four
+                       # transformed digits, a remainder tile with two of its four lines live and a plain digit alone in its tile
 ])
 def test_fused_phases_equal_oracle_and_unfused(L, K, alpha, batch, monkeypatch):
     mods, specials, ct = _case(L, K, 10 * L + alpha)
