@@ -16,7 +16,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <chrono>
 #include <functional>
 #include <algorithm>
 #include <array>
@@ -776,27 +775,12 @@ aloha_status aloha_vp_debug_tile_trace(aloha_vp *vp, void *dst, uint64_t bytes) 
 }
 #endif
 
-// Waiting for the stream: a blocked hipStreamSynchronize returns several microseconds after the stream has drained (the runtime
-// sleeps on the completion signal), which is most of a single small call (BASELINE config 2: a 6 us kernel).  Short waits are
-// therefore polled -- hipStreamQuery for at most kSyncPollUs -- before the blocking call takes over; long waits cost the CPU nothing
-// more than that.  (ALOHA_SYNC_POLL_US: the bound, 0 = block at once; A/B switch.)
-static hipError_t wait_for_stream(aloha_vp *vp) {
-  static const long poll_us = getenv("ALOHA_SYNC_POLL_US") ? atol(getenv("ALOHA_SYNC_POLL_US")) : 60;
-  if (poll_us > 0) {
-    const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(poll_us);
-    for (;;) {
-      const hipError_t e = hipStreamQuery(vp->stream);
-      if (e != hipErrorNotReady) return e;
-      if (std::chrono::steady_clock::now() >= t_end) break;
-    }
-  }
-  return hipStreamSynchronize(vp->stream);
-}
-
+// (Round 4: polling hipStreamQuery for up to 60 us before the blocking call was measured and dropped -- hipStreamSynchronize already
+// spins on the completion signal: one N = 2^12 transform with its synchronisation 18.2 us polled against 16.9 us, tests/perf/sync_latency.py.)
 aloha_status aloha_vp_sync(aloha_vp *vp) {
   if (!vp) return ALOHA_ERR_ARG;
   DeviceGuard dev_guard(vp);
-  HIPCK(vp, wait_for_stream(vp));
+  HIPCK(vp, hipStreamSynchronize(vp->stream));
   return check_fused(vp);
 }
 

@@ -1,7 +1,7 @@
 """One small call and its synchronisation, as a caller of the C ABI sees it (BASELINE config 2: one limb at N = 2^12; the reference's
-mul_plain at N = 2^13): microseconds per `run` + `sync`, median of 300.  A/B of ALOHA_SYNC_POLL_US (csrc/vp_engine.cpp: wait_for_stream):
+mul_plain at N = 2^13): microseconds per `run` + `sync`, median of 300.  (round 4: a polling wait in front of hipStreamSynchronize was measured with this and dropped: 18.2 against 16.9 us):
 
-    python tests/perf/sync_latency.py;  ALOHA_SYNC_POLL_US=0 python tests/perf/sync_latency.py"""
+    python tests/perf/sync_latency.py"""
 import json
 import os
 import sys
@@ -14,7 +14,7 @@ from aloha_amd import isa  # noqa: E402
 from aloha_amd import vp as avp  # noqa: E402
 
 SPM = 0
-res = {"ALOHA_SYNC_POLL_US": os.environ.get("ALOHA_SYNC_POLL_US", "(default)")}
+res = {}
 for logn in (12, 13, 16):
     n = 1 << logn
     q = avp.nth_prime(logn, 0)
