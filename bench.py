@@ -199,7 +199,8 @@ def configs_leg(device: int, budget_s: float = 85.0) -> dict:
     from aloha_amd import hybrid, isa, programs
     from aloha_amd import vp as avp
     t_start = time.perf_counter()
-    out = {"note": "one GPU, inputs resident in HBM; frac = algorithmic bytes / time / 8 TB/s; cpu_port_ms = the oracle (kind: port), one thread, same operation"}
+    out = {"note": "one GPU, inputs resident in HBM; every time after an untimed >= 100 ms of the same operation back to back (settled clocks, as the "
+                   "headline); frac = algorithmic bytes / time / 8 TB/s; cpu_port_ms = the oracle (kind: port), one thread, same operation"}
     SPM, KSK = 0, 1
 
     def timeit(fn, sync, reps):
@@ -207,7 +208,10 @@ def configs_leg(device: int, budget_s: float = 85.0) -> dict:
         # for 20-80 ms (seen as GAPS between launches in rocprofv3 traces, never as long kernels; the cause found in round 3 -- the
         # oracle's idle OpenMP workers spinning -- is fixed, profiles/r03_z_launch_gaps.txt), and one such pause inside a single
         # long loop is the whole figure for a 15 us operation
-        fn(); sync()
+        # ... and every figure is taken at SETTLED clocks, like the headline: an MI355X that idled while the host verified the previous
+        # config runs its first ~100 ms of launches up to 9 % slow (profiles/r04_configs_clock_settle.txt: HMult L = 24 0.270 ms over 30
+        # calls from idle, 0.250 over 400 and over 1500), and none of these loops is 100 ms long
+        settle(fn, sync, min_ms=100.0, max_ms=400.0)
         nblk = 5 if reps >= 50 else 3 if reps >= 15 else 1          # (one synchronisation per block: ~20 us spread over its calls)
         per = max(1, reps // nblk)
         ts = []
@@ -565,6 +569,7 @@ def keyswitch_leg(dist, backend, rank, world, local_rank, batch=1):
     from aloha_amd import hybrid, keyswitch
     from aloha_amd import vp as avp
     L, alpha, reps = 24, 4, 10
+    warm = 200 // batch                                          # untimed calls before the timed ones (clock settle; the same count on every rank)
     mods = [avp.nth_prime(LOGN, i) for i in range(L)]
     specials = [avp.nth_prime(LOGN, L + k) for k in range(alpha)]
     on_gpu = backend == "nccl"
@@ -591,6 +596,9 @@ def keyswitch_leg(dist, backend, rank, world, local_rank, batch=1):
             ks = hybrid.HybridKeySwitch(vp, N, mods, specials, alpha, world=world, rank=rank, exchange=ex, batch=batch)
             load(ks, lo)
             ks.multiply(); vp.sync()
+            for _ in range(warm):                                # untimed, the SAME count on every rank (collectives inside): settled clocks
+                ks.multiply()
+            vp.sync()
             dist.barrier(); torch.cuda.synchronize()
             sent0, recv0 = ex.bytes_sent, ex.bytes_received
             t0 = time.perf_counter()
@@ -615,6 +623,9 @@ def keyswitch_leg(dist, backend, rank, world, local_rank, batch=1):
         ks1 = hybrid.HybridKeySwitch(vp1, N, mods, specials, alpha, world=1, rank=0, exchange=keyswitch.Exchange(), batch=batch)
         load(ks1, lo1)
         ks1.multiply(); vp1.sync()
+        for _ in range(warm):
+            ks1.multiply()
+        vp1.sync()
         t0 = time.perf_counter()
         for _ in range(reps):
             ks1.multiply()
@@ -636,7 +647,7 @@ def keyswitch_leg_c_host(dist, rank, world, local_rank):
     carries the 128-byte ncclUniqueId and the timing reduce.  Verified against a single-rank C host on every rank."""
     from aloha_amd import ks as cks
     from aloha_amd import vp as avp
-    L, alpha, reps = 24, 4, 10
+    L, alpha, reps, warm = 24, 4, 10, 200
     mods = [avp.nth_prime(LOGN, i) for i in range(L)]
     specials = [avp.nth_prime(LOGN, L + k) for k in range(alpha)]
     dnum = -(-L // alpha)
@@ -660,6 +671,9 @@ def keyswitch_leg_c_host(dist, rank, world, local_rank):
     for mode in ("collective", "p2p"):
         k.set_p2p(mode == "p2p")
         k.multiply(); vp.sync()
+        for _ in range(warm):                                    # untimed, the same count on every rank: settled clocks
+            k.multiply()
+        vp.sync()
         dist.barrier()
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -673,6 +687,9 @@ def keyswitch_leg_c_host(dist, rank, world, local_rank):
     k.close(); vp.close()
     vp1, k1 = make(1, 0, None)
     k1.multiply(); vp1.sync()
+    for _ in range(warm):
+        k1.multiply()
+    vp1.sync()
     t0 = time.perf_counter()
     for _ in range(reps):
         k1.multiply()

@@ -36,6 +36,7 @@ def main() -> int:
     ap.add_argument("--rotations", type=int, default=8, help="--op hoisted: rotation steps per decomposition (one key each)")
     ap.add_argument("--many", action="store_true", help="--op hoisted: all rotations in one pass of the phases (rotate_hoisted_many)")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--settle-ms", type=float, default=120.0, help="untimed back-to-back calls before the timed ones (0 = none: times the clock ramp of an idle GPU)")
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--verify", action="store_true")
     ap.add_argument("--batch", type=int, default=1, help="ciphertexts per call (hybrid only)")
@@ -147,6 +148,12 @@ def main() -> int:
         torch.cuda.synchronize()
 
     op(); vp.sync()
+    # settled clocks (as bench.py): the first ~100 ms of launches after an idle spell run up to 9 % slow (profiles/r04_configs_clock_settle.txt)
+    t_settle = time.perf_counter()
+    while args.settle_ms and (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(8):
+            op()
+        vp.sync()
     barrier()
     launches0 = vp.stats()["kernel_launches"]
     t0 = time.perf_counter()
