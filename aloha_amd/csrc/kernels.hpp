@@ -209,7 +209,8 @@ hipError_t ntt_fwd16_rows(hipStream_t st, const LimbJob *d_inplace, const PrimeD
 // inverse column pass at N = 2^16, in place on the jobs' dst (`scaled`: some job carries its own last-stage scalar)
 hipError_t ntt_inv16_cols(hipStream_t st, const LimbJob *d_inplace, const PrimeDev *d_primes, uint32_t count, bool scaled, uint64_t *launches);
 // row pass of every group's transformed digits + inner product with the key, one launch
-hipError_t ntt_fwd16_rowdot(hipStream_t st, const RowDotGroup *d_groups, uint32_t ngroups, const PrimeDev *d_primes, uint64_t *launches);
+uint32_t rowdot_rows(const RowDotGroup *h_groups, uint32_t ngroups);   // rows per wave (1 / 2 / 4) for a launch over these groups
+hipError_t ntt_fwd16_rowdot(hipStream_t st, const RowDotGroup *d_groups, uint32_t ngroups, const PrimeDev *d_primes, uint32_t rows, uint64_t *launches);
 
 #ifdef ALOHA_EXPERIMENTS
 // Fused forward transform for N = 2^16 (experiments/ntt_tile_knobs.hip, ntt_fused_fwd_kernel): both passes in ONE persistent launch,

@@ -233,7 +233,11 @@ __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(R == 4 ?
   // The digits are walked in BLOCKS -- four transformed digits over the wave's R rows (R tiles), or one tile of DPT
   // left-over transformed / plain digits -- and every wave starts at a different block of the cycle: waves that share a
   // SIMD would otherwise all wait for their loads, then all compute, in step (the sum does not care about the order).
-  const uint32_t nquad = nt >> 2, ntr = (nt - 4 * nquad + DPT - 1) / DPT, npl = (np + DPT - 1) / DPT;
+  // The digits left over by the groups of four and the plain ones are ONE list, cut into tiles of DPT digits x R rows: a line is a digit
+  // of either kind (a plain digit riding in a tile with transformed lines is read again after the transform), so a group with
+  // 4 nquad + tr transformed and np plain digits costs ceil(tr / DPT) tiles with a transform and the rest of ceil((tr + np) / DPT) without.
+  const uint32_t nquad = nt >> 2, tr = nt - 4 * nquad;
+  const uint32_t ntr = (tr + DPT - 1) / DPT, npl = (tr + np + DPT - 1) / DPT - ntr;
   const uint32_t nblocks = nquad + ntr + npl;
   const uint32_t rowA = r0 + (L.lwA & (R - 1)), rowB = r0 + (L.lwB & (R - 1));
   const uint32_t offP = (rowA << 8) + L.plA;
@@ -294,12 +298,12 @@ __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(R == 4 ?
         for (int m = 0; m < 4; m++) { A[R - 1][m][0] = t[m][0]; A[R - 1][m][1] = t[m][1]; }
       }
     } else {
-      // -- DPT digits over the wave's R rows: transformed ones left over by the groups of four, or plain ones --------------
-      const bool transformed = b < nquad + ntr;
-      const uint32_t d0 = transformed ? 4 * nquad + (b - nquad) * DPT : nt + (b - nquad - ntr) * DPT;
-      const uint32_t end = transformed ? nt : nt + np;          // a tile holds digits of one kind
+      // -- DPT digits over the wave's R rows: the transformed ones left over by the groups of four, then the plain ones ----
+      const bool transformed = b < nquad + ntr;                 // the tile has transformed lines
+      const uint32_t d0 = 4 * nquad + (b - nquad) * DPT;
       const uint32_t d = d0 + (L.lwA >> DSH);                   // the lane's digit (A mapping)
-      const bool live = R == 4 ? true : d < end;                // (R = 4: one digit per tile, every line has it)
+      const bool live = R == 4 ? true : d < nt + np;            // (R = 4: one digit per tile, every line has it)
+      const bool plain_line = d >= nt;                           // (per line)
       const uint32_t dd = live ? d : d0;                         // (idle lines read the first digit's rows: defined data, zero weight)
       cgptr_t src = (cgptr_t)g->x[dd] + offP;
       u64 v[16];
@@ -309,9 +313,13 @@ __global__ __launch_bounds__(64 * S) __attribute__((amdgpu_waves_per_eu(R == 4 ?
         if constexpr (R == 1) row_fwd_core<true, FWD_MID, true, PRE>(v, lds, L, blkA, blkA, pr);   // (one row: one block for the wave)
         else row_fwd_core<false, FWD_MID, true, PRE, (R == 2 ? 7 : 3)>(v, lds, L, blkA, blkB, pr);
         gptr_t xo = (gptr_t)g->xout[dd];
-        if (live && xo) {
+        if (live && !plain_line && xo) {
 #pragma unroll
           for (int kk = 0; kk < 16; kk++) st_stream(&(xo + offP)[16 * kk], v[kk]);
+        }
+        if (plain_line) {                                        // a plain digit riding in the tile: its words as they are in memory
+#pragma unroll
+          for (int kk = 0; kk < 16; kk++) v[kk] = src[16 * kk];
         }
       } else {
 #pragma unroll
@@ -389,23 +397,37 @@ hipError_t ntt_fwd16_rows(hipStream_t st, const LimbJob *d_inplace, const PrimeD
   return hipGetLastError();
 }
 
-hipError_t ntt_fwd16_rowdot(hipStream_t st, const RowDotGroup *d_groups, uint32_t ngroups, const PrimeDev *d_primes, uint64_t *launches) {
+// Rows per wave for a launch, from its groups (host side, when the launch is planned).  Batches of ciphertexts (>= 96 groups) fill the chip
+// with four rows per wave and no idle lines.  Below that a wave's chain of tiles is what a launch costs, and the shapes differ in how many
+// tiles carry a transform: with two rows per wave the left-over digits travel two to a tile, with one row per wave four to a tile.  Per two rows of a group with 4 nquad + tr transformed and np plain digits:
+//   R = 2:  2 nquad + ceil(tr / 2) tiles with a transform, ceil((tr + np) / 2) - ceil(tr / 2) without
+//   R = 1:  2 nquad + 2 [tr > 0] with, 2 (ceil((tr + np) / 4) - [tr > 0]) without          (a tile without ~ half a tile with).  HMult L = 24, alpha = 4 (tr = 1 / 2): R = 2, 0.239 against 0.243 ms; rotate L = 32 (tr = 3 / 0): R = 1,
+// 0.315 against 0.344 ms (profiles/r04_w8_share_rowdot_rows.txt).  Very few groups (a rank's share at W = 8): R = 1 whatever the mix -- at two rows
+// the launch is one wave per SIMD and its time one wave's chain.
+uint32_t rowdot_rows(const RowDotGroup *h_groups, uint32_t ngroups) {
+  if (ngroups >= 96) return 4;
+  if (ngroups <= 10) return 1;
+  uint32_t c1 = 0, c2 = 0;                                       // in half transforms
+  for (uint32_t i = 0; i < ngroups; i++) {
+    const uint32_t nt = h_groups[i].nt, np = h_groups[i].np, nquad = nt >> 2, tr = nt - 4 * nquad, has = tr ? 1u : 0u;
+    c1 += 2 * (2 * nquad + 2 * has) + 2 * ((tr + np + 3) / 4 - has);
+    c2 += 2 * (2 * nquad + (tr + 1) / 2) + ((tr + np + 1) / 2 - (tr + 1) / 2);
+  }
+  return c1 <= c2 ? 1 : 2;
+}
+
+hipError_t ntt_fwd16_rowdot(hipStream_t st, const RowDotGroup *d_groups, uint32_t ngroups, const PrimeDev *d_primes, uint32_t rows, uint64_t *launches) {
   if (!ngroups) return hipSuccess;
-  // few groups (a key-switch of one ciphertext: 28 at L = 24): two rows per wave, twice the waves at 4 per SIMD; batches
-  // of ciphertexts fill the chip with four rows per wave and no idle lines.  (ALOHA_ROWDOT_ROWS: A/B timing switch)
+  // rows: rowdot_rows() of the launch's groups.  (ALOHA_ROWDOT_ROWS / ALOHA_ROWDOT_SPLIT: A/B timing switches)
   static const int forced = getenv("ALOHA_ROWDOT_ROWS") ? atoi(getenv("ALOHA_ROWDOT_ROWS")) : 0;
   static const int forced_split = getenv("ALOHA_ROWDOT_SPLIT") ? atoi(getenv("ALOHA_ROWDOT_SPLIT")) : 0;
-  const bool two = forced ? forced == 2 : ngroups < 96;
+  if (forced) rows = (uint32_t)forced;
   const bool split = forced_split ? forced_split == 2 : ngroups < 48;          // (S = 4, round 4: 0.292 against 0.271 ms; S = 1 equals S = 2 by now: profiles/r04_ks_kernel_experiments.txt)
-  // very few groups (a rank's share of a key-switch spread over 8 GPUs: 3-5): ONE row per wave -- at two rows the launch is one
-  // wave per SIMD and its time one wave's chain of tiles; half the chain on twice the waves (rank 0's share at W = 8: HMult L = 24
-  // 0.1027 -> 0.0978 ms, rotate L = 32 0.1164 -> 0.1056; at W = 4, 7 and 9 groups: -2 % and -4 %; at 14 groups and more it loses on the
-  // HMult (5 transformed digits: three tiles per row instead of two) and is within the noise on the rotate; four waves per row
-  // instead of two, or one: no better -- profiles/r04_w8_share_rowdot_rows.txt)
-  const bool one = forced ? forced == 1 : ngroups <= 10;
-  if (one) hipLaunchKernelGGL((ntt_rowdot_kernel<1, 2>), dim3(ngroups * 256), dim3(128), 0, st, d_groups, d_primes);
-  else if (two && split) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 2>), dim3(ngroups * 128), dim3(128), 0, st, d_groups, d_primes);
-  else if (two) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 1>), dim3(ngroups * 128), dim3(64), 0, st, d_groups, d_primes);
+  // one row per wave at W = 8 (3-5 groups): rank 0's share HMult L = 24 0.1027 -> 0.0978 ms, rotate L = 32 0.1164 -> 0.1056; four waves
+  // per row instead of two: slower (profiles/r04_w8_share_rowdot_rows.txt)
+  if (rows == 1) hipLaunchKernelGGL((ntt_rowdot_kernel<1, 2>), dim3(ngroups * 256), dim3(128), 0, st, d_groups, d_primes);
+  else if (rows == 2 && split) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 2>), dim3(ngroups * 128), dim3(128), 0, st, d_groups, d_primes);
+  else if (rows == 2) hipLaunchKernelGGL((ntt_rowdot_kernel<2, 1>), dim3(ngroups * 128), dim3(64), 0, st, d_groups, d_primes);
   else hipLaunchKernelGGL((ntt_rowdot_kernel<4, 1>), dim3(ngroups * 64), dim3(64), 0, st, d_groups, d_primes);
   if (launches) ++*launches;
   return hipGetLastError();

@@ -1819,13 +1819,14 @@ extern "C" aloha_status aloha_vp_run(aloha_vp *vp, uint32_t pc, uint64_t src0_ro
     if (s) return s;
     {
       const uint32_t cnt = (uint32_t)nT, n_uni = (uint32_t)uni.size(), n_glb = (uint32_t)glb.size(), n_grp = (uint32_t)rgroups.size();
+      const uint32_t dot_rows = aloha::k::rowdot_rows(rgroups.data(), n_grp);
       const hipError_t e = issue(vp, [=]() -> hipError_t {
         uint64_t launches = 0;
         const LimbJob *dj = (const LimbJob *)dJ;
         const TileDesc *dt = (const TileDesc *)dT;
         hipError_t e = aloha::k::ntt_fwd16_cols(st, dj, vp->d_primes, cnt, (const aloha::k::SumSrc *)dS, &launches);
         if (e == hipSuccess) e = aloha::k::ntt_fwd16_rows(st, dj + cnt, vp->d_primes, dt, n_uni, dt + n_uni, n_glb, (const aloha::k::RowEpi *)dE, &launches);
-        if (e == hipSuccess) e = aloha::k::ntt_fwd16_rowdot(st, (const aloha::k::RowDotGroup *)dG, n_grp, vp->d_primes, &launches);
+        if (e == hipSuccess) e = aloha::k::ntt_fwd16_rowdot(st, (const aloha::k::RowDotGroup *)dG, n_grp, vp->d_primes, dot_rows, &launches);
         vp->stats.kernel_launches += launches;
         vp->stats.ks_fused_launches += launches;
         return e;

@@ -18,7 +18,7 @@ for rep in 1 2 3; do
         python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v: inv', round(d['value']), 'NTT/s', round(d['ms_per_step'],4), 'ms/step')" >> $O
     fi
     for cfg in "--L 24 --alpha 4 --op multiply" "--L 32 --alpha 4 --op rotate"; do
-      r=$(ALOHA_VP_LIB=$lib timeout -k 10 200 python tools/bench_keyswitch_sharded.py $cfg --rom 16384 --reps 30 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f ms  launches %.0f' % (d['ms'], d['launches_per_op']))")
+      r=$(ALOHA_VP_LIB=$lib timeout -k 10 200 python tools/bench_keyswitch_sharded.py $cfg --rom 16384 --reps 150 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f ms  launches %.0f' % (d['ms'], d['launches_per_op']))")
       echo "$v | $cfg: $r" >> $O
     done
   done

@@ -11,7 +11,7 @@ for rep in 1 2 3; do
     v=${spec%%|*}; e=${spec#*|}; [ -z "$e" ] && e="A=1"
     lib=""; [ "$v" != "main" ] && lib=$R/aloha_amd/lib/libaloha_vp_$v.so
     for cfg in "--L 24 --alpha 4 --op multiply" "--L 32 --alpha 4 --op rotate"; do
-      r=$(env ALOHA_VP_LIB=$lib $e timeout -k 10 200 python tools/bench_keyswitch_sharded.py $cfg --rom 16384 --reps 30 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f ms  launches %.0f' % (d['ms'], d['launches_per_op']))")
+      r=$(env ALOHA_VP_LIB=$lib $e timeout -k 10 200 python tools/bench_keyswitch_sharded.py $cfg --rom 16384 --reps 150 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4f ms  launches %.0f' % (d['ms'], d['launches_per_op']))")
       echo "$spec | $cfg: $r" >> $O
     done
   done
