@@ -39,8 +39,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // canonicalised first: its Shoup product takes any 64-bit value.
 // (amdgpu_waves_per_eu(4) brings the <false> form from 136 to 128 VGPRs and four waves per SIMD without scratch: measured within
 // the noise, HMult 0.2703 against 0.2706 ms -- profiles/r04_ks_kernel_experiments.txt)
+#ifndef ALOHA_EPI_WAVES
+#define ALOHA_EPI_WAVES 1
+#endif
 template <bool UNIA>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1))) void ntt_row_epi_kernel(const LimbJob *__restrict__ jobs,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ALOHA_EPI_WAVES))) void ntt_row_epi_kernel(const LimbJob *__restrict__ jobs,
                                                                                                  const PrimeDev *__restrict__ primes,
                                                                                                  const TileDesc *__restrict__ tiles,
                                                                                                  const RowEpi *__restrict__ epis) {
