@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // Row pass (second pass of a forward transform) whose lines may end in an epilogue.  A line with an epilogue is not
 // canonicalised first: its Shoup product takes any 64-bit value.
 // (amdgpu_waves_per_eu(4) brings the <false> form from 136 to 128 VGPRs and four waves per SIMD without scratch: measured within
-// the noise, HMult 0.2703 against 0.2706 ms -- profiles/r04_ks_kernel_experiments.txt)
+// the noise, HMult 0.2703 against 0.2706 ms -- profiles/r04_ks_kernel_experiments.txt; again at settled clocks, ALOHA_EPI_WAVES=4:
+// HMult 0.2406 against 0.2391 ms, rotate 0.3155 against 0.3178)
 #ifndef ALOHA_EPI_WAVES
 #define ALOHA_EPI_WAVES 1
 #endif
