@@ -15,7 +15,7 @@ SPM = 0
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 n = 1 << logn
 B = int(sys.argv[2]) if len(sys.argv) > 2 else (1 << 28) // (8 * n)
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 with avp.VP(spm_rows=B * n // 128, ksk_rows=1, max_log_n=logn) as vp:
     P = int(os.environ.get("PRIMES", "16"))                       # limbs per prime = B / P (bench.py quotes N = 2^13 on one prime)
     mods = [avp.nth_prime(logn, i) for i in range(P) for _ in range(B // P)]
@@ -28,6 +28,11 @@ with avp.VP(spm_rows=B * n // 128, ksk_rows=1, max_log_n=logn) as vp:
     res = {}
     for name, inv in (("fwd", False), ("inv", True)):
         vp.ntt_rows(SPM, 0, 0, logn, mods, inverse=inv); vp.sync()
+        t_settle = time.perf_counter()                            # settled clocks (an idle GPU's first ~100 ms of launches run slow)
+        while time.perf_counter() - t_settle < 0.15:
+            for _ in range(10):
+                vp.ntt_rows(SPM, 0, 0, logn, mods, inverse=inv)
+            vp.sync()
         t0 = time.perf_counter()
         for _ in range(reps):
             vp.ntt_rows(SPM, 0, 0, logn, mods, inverse=inv)
