@@ -166,3 +166,19 @@ def test_chains_the_kernels_do_not_cover_fall_back_exactly():
         assert np.array_equal(res["window"][keep], res["oracle"][keep]), name
         if name == "regular_then_reload":                         # slot 8 is loaded again after the inner products: it must have been stored
             assert np.array_equal(res["window"][8], res["oracle"][8])
+
+
+@pytest.mark.parametrize("rows", [1, 2, 4])
+def test_every_shape_of_the_inner_product_kernel(rows):
+    """csrc/ntt_ks.hip picks the rows per wave of an inner-product launch from its groups (rowdot_rows); ALOHA_ROWDOT_ROWS forces one shape
+    for the whole process (read once), so each shape runs the 8- and the 24-group case above in a process of its own: tiles of four digits,
+    tiles shared by left-over transformed and plain digits (1, 2 or 4 of them per tile), idle lines -- all equal to the oracle machine."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ALOHA_ROWDOT_ROWS=str(rows))
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_ks_fused.py"),
+                        "-k", "test_fused_phases_equal_oracle_and_unfused and (10-2-2-2 or 7-1-1-1)"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2000:] + p.stderr[-1000:]
